@@ -1,0 +1,340 @@
+"""ctypes binding of the C ABI in include/fyprt.h (libfyprt.so).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded
+this module raises, loudly.  Nothing here imports or touches oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "csrc" / "libfyprt.so"
+
+# technique ids: SamplingTechniqueEnum.h:4-17
+BRUTE_FORCE, UNIFORM_SAMPLING, COSINE_WEIGHTED_SAMPLING, GGX_SAMPLING, BRDF_SAMPLING = 0, 1, 2, 3, 4
+LIGHT_SOURCE_SAMPLING, NEE, RESTIR_DI, RESTIR_GI = 5, 6, 7, 8
+TECHNIQUE_NAMES = ["BRUTE_FORCE", "UNIFORM_SAMPLING", "COSINE_WEIGHTED_SAMPLING", "GGX_SAMPLING", "BRDF_SAMPLING",
+                   "LIGHT_SOURCE_SAMPLING", "NEE", "RESTIR_DI", "RESTIR_GI"]
+
+BUF_ACCUM, BUF_IMAGE, BUF_PAYLOAD, BUF_DEPTH, BUF_NORMAL, BUF_DI, BUF_DI_PREV, BUF_GI, BUF_GI_PREV = range(9)
+
+# numpy views of the per-pixel records (Ray.h:13-22, ReSTIR_DI_Reservoir.cuh:9-16, ReSTIR_GI_Reservoir.cuh:9-27)
+PAYLOAD_DTYPE = np.dtype([("hitDistance", "<f4"), ("worldPosition", "<f4", 3), ("worldNormal", "<f4", 3),
+                          ("u", "<f4"), ("v", "<f4"), ("objectIndex", "<i4")])
+DI_DTYPE = np.dtype([("indexEmissive", "<u4"), ("weightEmissive", "<f4"), ("emissivePDF", "<f4"),
+                     ("weightSum", "<f4"), ("M", "<u4")])
+GI_DTYPE = np.dtype([("visiblePoint", "<f4", 3), ("visibleNormal", "<f4", 2), ("samplePoint", "<f4", 3),
+                     ("sampleNormal", "<f4", 2), ("Lo", "<f4", 3), ("randSeed", "<u4"), ("samplePDF", "<f4"),
+                     ("weightSample", "<f4"), ("M", "<u4"), ("weightSum", "<f4")])
+assert PAYLOAD_DTYPE.itemsize == 40 and DI_DTYPE.itemsize == 20 and GI_DTYPE.itemsize == 72
+BUFFER_DTYPES = {BUF_ACCUM: np.dtype(("<f4", 4)), BUF_IMAGE: np.dtype("<u4"), BUF_PAYLOAD: PAYLOAD_DTYPE,
+                 BUF_DEPTH: np.dtype("<f4"), BUF_NORMAL: np.dtype(("<f4", 2)), BUF_DI: DI_DTYPE, BUF_DI_PREV: DI_DTYPE,
+                 BUF_GI: GI_DTYPE, BUF_GI_PREV: GI_DTYPE}
+
+VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("uv", "<f4", 2)])
+TRIANGLE_DTYPE = np.dtype([("v0", "<u4"), ("v1", "<u4"), ("v2", "<u4"), ("materialIndex", "<i4")])
+MATERIAL_DTYPE = np.dtype([("isUseAlbedoMap", "<u4"), ("albedo", "<f4", 3), ("albedoMapIndex", "<u4"),
+                           ("roughness", "<f4"), ("metallic", "<f4"), ("emissionColor", "<f4", 3),
+                           ("emissionPower", "<f4")])
+MESH_DTYPE = np.dtype([("firstTriangle", "<u4"), ("triangleCount", "<u4"), ("materialIndex", "<i4")])
+LT_NODE_DTYPE = np.dtype([("energy", "<f4"), ("numEmitters", "<u4"), ("left", "<u4"), ("rightOrEmitter", "<u4"),
+                          ("isLeaf", "<u4"), ("coneAxis", "<f4", 3), ("theta_o", "<f4"), ("theta_e", "<f4"),
+                          ("boxLo", "<f4", 3), ("boxHi", "<f4", 3), ("boxCentroid", "<f4", 3), ("_pad", "<u4")])
+assert VERTEX_DTYPE.itemsize == 32 and TRIANGLE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 44
+assert MESH_DTYPE.itemsize == 12 and LT_NODE_DTYPE.itemsize == 80
+BVH_NODE_DTYPE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3),
+                           ("child0", "<i4"), ("child1", "<i4"), ("pad", "<i4", 2)])
+BVH_TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("tri", "<u4"), ("pad", "<u4", 2)])
+assert BVH_NODE_DTYPE.itemsize == 64 and BVH_TRI_DTYPE.itemsize == 48
+
+
+class Settings(C.Structure):  # RenderingSettings.h:5-22 (52 B) with the reference's defaults
+    _fields_ = [("to_accumulate", C.c_uint8), ("_pad0", C.c_uint8 * 3), ("light_bounces", C.c_int32),
+                ("sample_count", C.c_int32), ("sky_color", C.c_float * 3), ("technique", C.c_int32),
+                ("light_candidate_count", C.c_int32), ("rand_seed", C.c_uint32), ("use_temporal_reuse", C.c_uint8),
+                ("use_spatial_reuse", C.c_uint8), ("_pad1", C.c_uint8 * 2), ("temporal_history_limit", C.c_int32),
+                ("spatial_neighbor_num", C.c_int32), ("spatial_neighbor_radius", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.to_accumulate = 1
+        self.light_bounces = 1
+        self.sample_count = 1
+        self.sky_color = (C.c_float * 3)(1.0, 1.0, 1.0)
+        self.technique = BRUTE_FORCE
+        self.light_candidate_count = 4
+        self.rand_seed = 1
+        self.use_temporal_reuse = 0
+        self.use_spatial_reuse = 0
+        self.temporal_history_limit = 2
+        self.spatial_neighbor_num = 5
+        self.spatial_neighbor_radius = 30
+        for k, v in kw.items():
+            if k == "sky_color":
+                self.sky_color = (C.c_float * 3)(*v)
+            else:
+                if not hasattr(self, k):
+                    raise AttributeError(k)
+                setattr(self, k, v)
+
+
+assert C.sizeof(Settings) == 52
+
+
+class Texture(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class LightTrees(C.Structure):
+    _fields_ = [("tlas_nodes", C.c_void_p), ("tlas_node_count", C.c_uint32), ("tlas_root", C.c_uint32),
+                ("blas_nodes", C.c_void_p), ("blas_first", C.c_void_p), ("blas_count", C.c_void_p),
+                ("blas_root", C.c_void_p)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertex_count", C.c_uint32),
+                ("triangles", C.c_void_p), ("triangle_count", C.c_uint32), ("triangle_stride", C.c_uint32),
+                ("materials", C.c_void_p), ("material_count", C.c_uint32),
+                ("meshes", C.c_void_p), ("mesh_count", C.c_uint32),
+                ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32),
+                ("emissive_triangles", C.c_void_p), ("emissive_count", C.c_uint32),
+                ("light_trees", C.POINTER(LightTrees))]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("projection", C.c_float * 16), ("view", C.c_float * 16), ("prev_projection", C.c_float * 16),
+                ("prev_view", C.c_float * 16), ("inverse_projection", C.c_float * 16), ("inverse_view", C.c_float * 16),
+                ("position", C.c_float * 3), ("viewport_width", C.c_uint32), ("viewport_height", C.c_uint32)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_float), ("kernel_ms_part", C.c_float * 4), ("rays", C.c_uint64),
+                ("launches", C.c_uint32)]
+
+
+EXPORTED_SYMBOLS = [
+    "fyprt_create", "fyprt_destroy", "fyprt_last_error", "fyprt_resize", "fyprt_set_rows", "fyprt_upload_scene",
+    "fyprt_set_camera", "fyprt_render", "fyprt_render_async", "fyprt_synchronize", "fyprt_readback",
+    "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer",
+    "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees",
+    "fyprt_set_ray_counting", "fyprt_version",
+]
+
+
+class FyprtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """Load libfyprt.so (built by __graft_entry__.build() / csrc/build.sh). Fails loudly."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise FyprtError(f"HIP extension not built: {p} is missing. Run `python __graft_entry__.py build` "
+                         f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(str(p))
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    lib.fyprt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.fyprt_destroy.argtypes = [vp]
+    lib.fyprt_destroy.restype = None
+    lib.fyprt_last_error.argtypes = [vp]
+    lib.fyprt_last_error.restype = C.c_char_p
+    lib.fyprt_resize.argtypes = [vp, u32, u32]
+    lib.fyprt_set_rows.argtypes = [vp, u32, u32, u32]
+    lib.fyprt_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    lib.fyprt_set_camera.argtypes = [vp, C.POINTER(CameraDesc)]
+    lib.fyprt_render.argtypes = [vp, C.POINTER(Settings), C.POINTER(FrameStats)]
+    lib.fyprt_render_async.argtypes = [vp, C.POINTER(Settings)]
+    lib.fyprt_synchronize.argtypes = [vp]
+    lib.fyprt_readback.argtypes = [vp, vp, vp]
+    lib.fyprt_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    lib.fyprt_set_external_image.argtypes = [vp, vp]
+    lib.fyprt_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.fyprt_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.fyprt_reset_frame_index.argtypes = [vp]
+    lib.fyprt_frame_index.argtypes = [vp]
+    lib.fyprt_frame_index.restype = u32
+    lib.fyprt_export_bvh.argtypes = [vp, vp, C.POINTER(u32), vp, C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]
+    lib.fyprt_export_lighttrees.argtypes = [vp, vp, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(u32), vp, vp, vp]
+    lib.fyprt_set_ray_counting.argtypes = [vp, C.c_int]
+    lib.fyprt_version.restype = C.c_char_p
+    for f in EXPORTED_SYMBOLS:
+        fn = getattr(lib, f)
+        if fn.restype is C.c_int:
+            pass
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_scene_desc(scene, light_trees: dict | None = None):
+    """Build a fyprt_scene_desc from a host `Scene` (fypraytracer_amd.scene.Scene).
+    Returns (desc, keepalive) — keep `keepalive` referenced while the desc is in use."""
+    keep = []
+    v = np.ascontiguousarray(scene.world_vertices, dtype=VERTEX_DTYPE)
+    t = np.ascontiguousarray(scene.triangles, dtype=TRIANGLE_DTYPE)
+    m = np.ascontiguousarray(scene.materials_array(), dtype=MATERIAL_DTYPE)
+    ms = np.ascontiguousarray(scene.meshes_array(), dtype=MESH_DTYPE)
+    keep += [v, t, m, ms]
+    d = SceneDesc()
+    d.vertices, d.vertex_count = _ptr(v), len(v)
+    d.triangles, d.triangle_count, d.triangle_stride = _ptr(t), len(t), TRIANGLE_DTYPE.itemsize
+    d.materials, d.material_count = _ptr(m), len(m)
+    d.meshes, d.mesh_count = _ptr(ms), len(ms)
+    texs = (Texture * max(1, len(scene.textures)))()
+    for i, px in enumerate(scene.textures):
+        px = np.ascontiguousarray(px, dtype=np.uint32)
+        keep.append(px)
+        texs[i].pixels, texs[i].height, texs[i].width = _ptr(px), px.shape[0], px.shape[1]
+    keep.append(texs)
+    d.textures = C.cast(texs, C.POINTER(Texture))
+    d.texture_count = len(scene.textures)
+    d.emissive_triangles, d.emissive_count = None, 0
+    if light_trees is not None:
+        lt = LightTrees()
+        arrs = {k: np.ascontiguousarray(light_trees[k]) for k in ("tlas", "blas", "blas_first", "blas_count", "blas_root")}
+        keep.append(arrs)
+        lt.tlas_nodes, lt.tlas_node_count, lt.tlas_root = _ptr(arrs["tlas"]), len(arrs["tlas"]), int(light_trees["tlas_root"])
+        lt.blas_nodes, lt.blas_first = _ptr(arrs["blas"]), _ptr(arrs["blas_first"])
+        lt.blas_count, lt.blas_root = _ptr(arrs["blas_count"]), _ptr(arrs["blas_root"])
+        keep.append(lt)
+        d.light_trees = C.pointer(lt)
+    return d, keep
+
+
+def make_camera_desc(cam) -> CameraDesc:
+    """From fypraytracer_amd.scene.Camera (column-major float32 4x4 matrices)."""
+    c = CameraDesc()
+    for name, mat in (("projection", cam.projection), ("view", cam.view), ("prev_projection", cam.prev_projection),
+                      ("prev_view", cam.prev_view), ("inverse_projection", cam.inverse_projection),
+                      ("inverse_view", cam.inverse_view)):
+        flat = np.asarray(mat, dtype=np.float32).reshape(16)   # stored column-major already (see scene.Camera)
+        setattr(c, name, (C.c_float * 16)(*flat.tolist()))
+    c.position = (C.c_float * 3)(*[float(x) for x in cam.position])
+    c.viewport_width, c.viewport_height = int(cam.width), int(cam.height)
+    return c
+
+
+class Context:
+    """One renderer context on one GPU — the Python face of the reference's `Renderer`
+    (Renderer.h:41-56): resize / upload_scene / set_camera / render / readback."""
+
+    def __init__(self, device: int = 0, lib: C.CDLL | None = None):
+        self.lib = lib or load_library()
+        h = C.c_void_p()
+        rc = self.lib.fyprt_create(device, C.byref(h))
+        if rc != 0:
+            raise FyprtError(f"fyprt_create({device}) failed: {self.lib.fyprt_last_error(None).decode()}")
+        self.h = h
+        self.width = self.height = 0
+        self._keep = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FyprtError(f"fyprt error {rc}: {self.lib.fyprt_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fyprt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resize(self, width, height):
+        self._check(self.lib.fyprt_resize(self.h, width, height))
+        self.width, self.height = width, height
+
+    def set_rows(self, row_begin, row_end, halo_rows=0):
+        self._check(self.lib.fyprt_set_rows(self.h, row_begin, row_end, halo_rows))
+
+    def upload_scene(self, scene, light_trees=None):
+        d, keep = make_scene_desc(scene, light_trees)
+        self._check(self.lib.fyprt_upload_scene(self.h, C.byref(d)))
+
+    def set_camera(self, cam):
+        c = make_camera_desc(cam)
+        self._check(self.lib.fyprt_set_camera(self.h, C.byref(c)))
+
+    def render(self, settings: Settings) -> FrameStats:
+        st = FrameStats()
+        self._check(self.lib.fyprt_render(self.h, C.byref(settings), C.byref(st)))
+        return st
+
+    def render_async(self, settings: Settings):
+        self._check(self.lib.fyprt_render_async(self.h, C.byref(settings)))
+
+    def synchronize(self):
+        self._check(self.lib.fyprt_synchronize(self.h))
+
+    def readback(self, want_accum=True):
+        n = self.width * self.height
+        img = np.empty(n, dtype=np.uint32)
+        acc = np.empty((n, 4), dtype=np.float32) if want_accum else None
+        self._check(self.lib.fyprt_readback(self.h, _ptr(img), _ptr(acc)))
+        return img.reshape(self.height, self.width), (acc.reshape(self.height, self.width, 4) if want_accum else None)
+
+    def read_buffer(self, which) -> np.ndarray:
+        dt = BUFFER_DTYPES[which]
+        out = np.empty(self.width * self.height, dtype=dt)
+        self._check(self.lib.fyprt_read_buffer(self.h, which, _ptr(out), out.nbytes))
+        return out
+
+    def image_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.fyprt_image_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def set_external_image(self, device_ptr: int):
+        self._check(self.lib.fyprt_set_external_image(self.h, C.c_void_p(device_ptr)))
+
+    def stream(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.fyprt_stream(self.h, C.byref(p)))
+        return p.value or 0
+
+    def reset_frame_index(self):
+        self._check(self.lib.fyprt_reset_frame_index(self.h))
+
+    @property
+    def frame_index(self) -> int:
+        return int(self.lib.fyprt_frame_index(self.h))
+
+    def set_ray_counting(self, on: bool):
+        self._check(self.lib.fyprt_set_ray_counting(self.h, 1 if on else 0))
+
+    def export_bvh(self):
+        nn, nt, root, depth = C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_uint32()
+        self._check(self.lib.fyprt_export_bvh(self.h, None, C.byref(nn), None, C.byref(nt), C.byref(root), C.byref(depth)))
+        nodes = np.empty(nn.value, dtype=BVH_NODE_DTYPE)
+        tris = np.empty(nt.value, dtype=BVH_TRI_DTYPE)
+        self._check(self.lib.fyprt_export_bvh(self.h, _ptr(nodes), C.byref(nn), _ptr(tris), C.byref(nt), C.byref(root), C.byref(depth)))
+        return {"nodes": nodes, "tris": tris, "root": root.value, "max_depth": depth.value}
+
+    def export_lighttrees(self, mesh_count: int):
+        tc, tr, bt = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        first = np.zeros(mesh_count, dtype=np.uint32)
+        count = np.zeros(mesh_count, dtype=np.uint32)
+        root = np.zeros(mesh_count, dtype=np.uint32)
+        self._check(self.lib.fyprt_export_lighttrees(self.h, None, C.byref(tc), C.byref(tr), None, C.byref(bt), None, None, None))
+        tlas = np.zeros(tc.value, dtype=LT_NODE_DTYPE)
+        blas = np.zeros(bt.value, dtype=LT_NODE_DTYPE)
+        self._check(self.lib.fyprt_export_lighttrees(self.h, _ptr(tlas), C.byref(tc), C.byref(tr), _ptr(blas), C.byref(bt),
+                                                     _ptr(first), _ptr(count), _ptr(root)))
+        return {"tlas": tlas, "tlas_root": tr.value, "blas": blas, "blas_first": first, "blas_count": count, "blas_root": root}

@@ -1,0 +1,161 @@
+// Host builder of the library's own two-level acceleration structure (layout: rt_host.h).
+// Binned SAH (16 bins, 3 axes) over triangle centroids, up to 4 triangles per leaf, nodes in
+// pre-order so the top of each tree is contiguous in memory; below depth 48 it switches to
+// object-median splits so the traversal stack is bounded (maxDepth is exported and checked
+// against the kernel's stack capacity).  This replaces the reference's recursive builder
+// (BVH.cpp:146-309, one triangle per leaf, unordered) — the tree SHAPE is ours; the set of
+// triangles a ray can reach is the same, and the closest hit is found with the reference's
+// own Möller–Trumbore arithmetic, so results match except for exact-tie order.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include "rt_host.h"
+
+namespace rth {
+namespace {
+
+struct Box {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* l, const float* h) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); } }
+    void grow(const Box& b) { grow(b.lo, b.hi); }
+    float area() const { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return (dx < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx); }
+};
+struct Prim { Box b; float c[3]; uint32_t id; };
+
+struct Builder {
+    std::vector<Node> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf;
+    std::function<int32_t(const Prim*, uint32_t, uint32_t)> makeLeaf;   // (prims, count, depth) -> leaf ref
+    static constexpr int kBins = 16;
+
+    int32_t build(Prim* p, uint32_t first, uint32_t last, uint32_t depth, Box& outBox) {
+        const uint32_t count = last - first;
+        Box nb, cb;
+        for (uint32_t i = first; i < last; ++i) { nb.grow(p[i].b); cb.grow(p[i].c, p[i].c); }
+        outBox = nb;
+        int bestAxis = -1, bestBin = -1; float bestCost = FLT_MAX;
+        if (count > 1 && depth < 48) {
+            for (int axis = 0; axis < 3; ++axis) {
+                const float cmin = cb.lo[axis], cmax = cb.hi[axis];
+                if (!(cmax > cmin)) continue;
+                Box bb[kBins]; uint32_t bc[kBins] = {0};
+                const float scale = (float)kBins / (cmax - cmin);
+                for (uint32_t i = first; i < last; ++i) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((p[i].c[axis] - cmin) * scale)));
+                    bc[b]++; bb[b].grow(p[i].b);
+                }
+                float rightArea[kBins]; uint32_t rightCount[kBins]; Box acc; uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); n += bc[b]; rightArea[b] = acc.area(); rightCount[b] = n; }
+                acc = Box(); n = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bb[b]); n += bc[b];
+                    if (n == 0 || rightCount[b + 1] == 0) continue;
+                    float cost = acc.area() * (float)n + rightArea[b + 1] * (float)rightCount[b + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+                }
+            }
+        }
+        if (count <= maxLeaf) {
+            const float leafCost = (float)count * nb.area();
+            const float splitCost = (bestAxis >= 0) ? 1.0f * nb.area() + bestCost : FLT_MAX;
+            if (count == 1 || leafCost <= splitCost) { maxDepth = std::max(maxDepth, depth); return makeLeaf(p + first, count, depth); }
+        }
+        uint32_t mid;
+        if (bestAxis >= 0) {
+            const float cmin = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cmin);
+            Prim* m = std::partition(p + first, p + last, [&](const Prim& q) {
+                return std::min(kBins - 1, std::max(0, (int)((q.c[bestAxis] - cmin) * scale))) <= bestBin; });
+            mid = (uint32_t)(m - p);
+        } else {
+            int axis = 0; float ext = -1.0f;
+            for (int a = 0; a < 3; ++a) { float e = cb.hi[a] - cb.lo[a]; if (e > ext) { ext = e; axis = a; } }
+            mid = first + count / 2;
+            std::nth_element(p + first, p + mid, p + last, [axis](const Prim& a, const Prim& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id); });
+        }
+        if (mid == first || mid == last) mid = first + count / 2;
+        const int32_t self = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box b0, b1;
+        int32_t c0 = build(p, first, mid, depth + 1, b0);
+        int32_t c1 = build(p, mid, last, depth + 1, b1);
+        Node& n = nodes[self];
+        std::memcpy(n.lo0, b0.lo, 12); std::memcpy(n.hi0, b0.hi, 12); std::memcpy(n.lo1, b1.lo, 12); std::memcpy(n.hi1, b1.hi, 12);
+        n.child0 = c0; n.child1 = c1; n.pad[0] = n.pad[1] = 0;
+        return self;
+    }
+};
+
+inline const uint32_t* triIdx(const uint8_t* tris, uint32_t stride, uint32_t i) { return reinterpret_cast<const uint32_t*>(tris + (size_t)i * stride); }
+
+}  // namespace
+
+void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
+                   uint32_t meshCount, SceneBVH& out) {
+    out = SceneBVH();
+    struct MeshOut { std::vector<Node> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
+    std::vector<MeshOut> mo(meshCount);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int m = 0; m < (int)meshCount; ++m) {
+        const fyprt_mesh& me = meshes[m];
+        if (me.triangle_count == 0) continue;
+        std::vector<Prim> prims(me.triangle_count);
+        for (uint32_t i = 0; i < me.triangle_count; ++i) {
+            const uint32_t t = me.first_triangle + i; const uint32_t* v = triIdx(tris, triStride, t);
+            Prim& p = prims[i]; p.id = t;
+            for (int k = 0; k < 3; ++k) p.b.grow(verts[v[k]].position, verts[v[k]].position);
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
+        }
+        MeshOut& o = mo[m];
+        Builder b; b.maxLeaf = 4;
+        b.makeLeaf = [&](const Prim* p, uint32_t count, uint32_t) -> int32_t {
+            const uint32_t first = (uint32_t)o.tris.size();
+            for (uint32_t i = 0; i < count; ++i) {
+                const uint32_t* v = triIdx(tris, triStride, p[i].id);
+                const float *p0 = verts[v[0]].position, *p1 = verts[v[1]].position, *p2 = verts[v[2]].position;
+                Tri t; std::memset(&t, 0, sizeof t);
+                for (int a = 0; a < 3; ++a) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; }
+                t.tri = p[i].id;
+                o.tris.push_back(t);
+            }
+            return ~(int32_t)((first << 2) | (count - 1));
+        };
+        o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, o.box);
+        o.nodes.swap(b.nodes); o.depth = b.maxDepth; o.valid = true;
+    }
+    // TLAS over the valid meshes; leaves are BLAS roots (relocated below)
+    std::vector<Prim> mp;
+    for (uint32_t m = 0; m < meshCount; ++m) if (mo[m].valid) {
+        Prim p; p.b = mo[m].box; p.id = m; for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]); mp.push_back(p);
+    }
+    if (mp.empty()) return;
+    std::vector<uint32_t> leafDepth(meshCount, 0);
+    Builder tb; tb.maxLeaf = 1;
+    tb.makeLeaf = [&](const Prim* p, uint32_t, uint32_t depth) -> int32_t { leafDepth[p[0].id] = depth; return INT32_MIN + (int32_t)p[0].id; };   // placeholder
+    Box sceneBox;
+    int32_t troot = tb.build(mp.data(), 0, (uint32_t)mp.size(), 0, sceneBox);
+    out.tlasNodes = (uint32_t)tb.nodes.size();
+    std::vector<uint32_t> nodeOff(meshCount, 0), triOff(meshCount, 0);
+    uint32_t no = out.tlasNodes, to = 0;
+    for (uint32_t m = 0; m < meshCount; ++m) { nodeOff[m] = no; triOff[m] = to; no += (uint32_t)mo[m].nodes.size(); to += (uint32_t)mo[m].tris.size(); }
+    auto relocate = [&](int32_t ref, uint32_t m) -> int32_t {
+        if (ref >= 0) return ref + (int32_t)nodeOff[m];
+        uint32_t code = (uint32_t)~ref; uint32_t first = (code >> 2) + triOff[m];
+        return ~(int32_t)((first << 2) | (code & 3u));
+    };
+    auto resolveTlas = [&](int32_t ref) -> int32_t {
+        if (ref >= 0) return ref;                                    // TLAS inner node (already global: TLAS is first)
+        uint32_t m = (uint32_t)(ref - INT32_MIN);
+        return relocate(mo[m].root, m);
+    };
+    out.nodes.reserve(no); out.tris.reserve(to);
+    for (Node n : tb.nodes) { n.child0 = resolveTlas(n.child0); n.child1 = resolveTlas(n.child1); out.nodes.push_back(n); }
+    for (uint32_t m = 0; m < meshCount; ++m) {
+        for (Node n : mo[m].nodes) { n.child0 = relocate(n.child0, m); n.child1 = relocate(n.child1, m); out.nodes.push_back(n); }
+        out.tris.insert(out.tris.end(), mo[m].tris.begin(), mo[m].tris.end());
+        if (mo[m].valid) out.maxDepth = std::max(out.maxDepth, leafDepth[m] + mo[m].depth);
+    }
+    out.rootRef = resolveTlas(troot);
+}
+
+}  // namespace rth

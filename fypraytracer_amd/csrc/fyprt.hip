@@ -1,0 +1,428 @@
+// libfyprt.so — C ABI (include/fyprt.h) over the gfx950 kernels of rt_kernels.h.
+// Owns all device memory of one renderer context; everything stays resident in HBM between
+// frames (the reference re-allocates and round-trips ~100 MB over PCIe per 1080p frame,
+// Renderer.cu:37-53, :70, :244-283 — SURVEY.md §8 a14).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "rt_host.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_createError;
+
+bool g_hostOnlyAlloc = false;   // set while a host-only context ingests a scene (no device allocations)
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release(); n = count;
+        if (count == 0 || g_hostOnlyAlloc) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// host mat4 product, same operation order as the device / glm (column j = ((a0*bj.x + a1*bj.y) + a2*bj.z) + a3*bj.w)
+void matmul_cm(const float* a, const float* b, float* out) {
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r) {
+            float t = a[0 * 4 + r] * b[j * 4 + 0] + a[1 * 4 + r] * b[j * 4 + 1];
+            t = t + a[2 * 4 + r] * b[j * 4 + 2];
+            t = t + a[3 * 4 + r] * b[j * 4 + 3];
+            out[j * 4 + r] = t;
+        }
+}
+
+}  // namespace
+
+struct fyprt_context {
+    int device = 0; hipStream_t stream = nullptr; std::string err; bool hostOnly = false;
+    hipEvent_t ev[6] = {};
+    uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
+    bool haveScene = false, haveCamera = false, countRays = false;
+    // per-pixel buffers
+    DevBuf<float4> accum; DevBuf<uint32_t> image; DevBuf<Payload> payload; DevBuf<float> depth; DevBuf<f2> normalA, normalB;
+    DevBuf<DIRes> di, diPrev; DevBuf<GIRes> gi, giPrev; bool normalFlip = false;
+    uint32_t* externalImage = nullptr;
+    // scene
+    DevBuf<float4> nodes, leafTris, triPos, triShade, mats; DevBuf<DevTexture> texTable; std::vector<DevBuf<uint32_t>> texPixels;
+    DevBuf<uint32_t> emissive; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot;
+    DevBuf<unsigned long long> rayCounter;
+    DevScene dsc{}; DevCamera dcam{};
+    rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
+    int lastLaunches = 0;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    int hip(hipError_t e, const char* what) {
+        if (e == hipSuccess) return FYPRT_OK;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        std::fprintf(stderr, "fyprt: %s\n", err.c_str());     // the reference prints and continues (Renderer.cu:29-47)
+        return FYPRT_EHIP;
+    }
+};
+
+#define HIPCHK(ctx, call) do { int _rc = (ctx)->hip((call), #call); if (_rc != FYPRT_OK) return _rc; } while (0)
+
+extern "C" {
+
+const char* fyprt_version(void) { return "fyprt 0.1.0 gfx950 (wave64, LDS traversal stack, fp-contract off)"; }
+
+int fyprt_create(int device_ordinal, fyprt_context** out) {
+    if (!out) { g_createError = "fyprt_create: out is NULL"; return FYPRT_EINVAL; }
+    *out = nullptr;
+    if (device_ordinal == -1) {          // host-only context: scene ingestion + builders + exports, no device (CPU tests)
+        auto* hc = new fyprt_context(); hc->device = -1; hc->hostOnly = true; *out = hc; return FYPRT_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) { g_createError = std::string("no HIP device: ") + hipGetErrorString(e); return FYPRT_EHIP; }
+    if (device_ordinal < 0 || device_ordinal >= count) { g_createError = "device ordinal out of range"; return FYPRT_EINVAL; }
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) { g_createError = std::string("hipSetDevice: ") + hipGetErrorString(e); return FYPRT_EHIP; }
+    auto* c = new fyprt_context(); c->device = device_ordinal;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    (void)c->rayCounter.alloc(1);
+    (void)hipMemset(c->rayCounter.p, 0, 8);
+    *out = c;
+    return FYPRT_OK;
+}
+
+void fyprt_destroy(fyprt_context* c) {
+    if (!c) return;
+    if (c->hostOnly) { delete c; return; }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->accum.release(); c->image.release(); c->payload.release(); c->depth.release(); c->normalA.release(); c->normalB.release();
+    c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release();
+    c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
+    for (auto& t : c->texPixels) t.release();
+    c->emissive.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
+    c->rayCounter.release();
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* fyprt_last_error(const fyprt_context* c) { return c ? c->err.c_str() : g_createError.c_str(); }
+
+int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
+    if (!c) return FYPRT_EINVAL;
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 31)) return c->fail(FYPRT_EINVAL, "fyprt_resize: bad size");
+    if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context (device -1) has no device buffers");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)w * h;
+    HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
+    HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
+    HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n));
+    // cudaMemset(…, 0, …) of every buffer: Renderer.cu:333-355, :372, :393, :414
+    HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->image.p, 0, c->image.bytes(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->payload.p, 0, c->payload.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->depth.p, 0, c->depth.bytes(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->normalA.p, 0, c->normalA.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->normalB.p, 0, c->normalB.bytes(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->di.p, 0, c->di.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->diPrev.p, 0, c->diPrev.bytes(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->gi.p, 0, c->gi.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->giPrev.p, 0, c->giPrev.bytes(), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->externalImage = nullptr;
+    if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
+    return FYPRT_OK;
+}
+
+int fyprt_set_rows(fyprt_context* c, uint32_t b, uint32_t e, uint32_t halo) {
+    if (!c) return FYPRT_EINVAL;
+    if (c->H == 0) return c->fail(FYPRT_ESTATE, "fyprt_set_rows before fyprt_resize");
+    if (b >= e || e > c->H) return c->fail(FYPRT_EINVAL, "fyprt_set_rows: need row_begin < row_end <= height");
+    c->rowBegin = b; c->rowEnd = e; c->halo = halo; c->rowsSet = true;
+    return FYPRT_OK;
+}
+
+static int upload(fyprt_context* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0 || c->hostOnly) return FYPRT_OK;
+    return c->hip(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
+}
+
+int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
+    if (!c || !s) return FYPRT_EINVAL;
+    if ((s->triangle_count && (!s->triangles || !s->vertices || s->triangle_stride < 16)) || (s->mesh_count && !s->meshes) ||
+        (s->material_count && !s->materials))
+        return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: NULL array with non-zero count");
+    if (!c->hostOnly) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    const uint8_t* tb = (const uint8_t*)s->triangles;
+    auto tri = [&](uint32_t i) { return reinterpret_cast<const uint32_t*>(tb + (size_t)i * s->triangle_stride); };
+    for (uint32_t i = 0; i < s->triangle_count; ++i) {
+        const uint32_t* t = tri(i);
+        if (t[0] >= s->vertex_count || t[1] >= s->vertex_count || t[2] >= s->vertex_count || (int32_t)t[3] < 0 || t[3] >= s->material_count)
+            return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: triangle " + std::to_string(i) + " references a vertex/material out of range");
+    }
+    uint64_t covered = 0;
+    for (uint32_t m = 0; m < s->mesh_count; ++m) {
+        const fyprt_mesh& me = s->meshes[m];
+        if ((uint64_t)me.first_triangle + me.triangle_count > s->triangle_count || me.material_index < 0 || (uint32_t)me.material_index >= s->material_count)
+            return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: mesh " + std::to_string(m) + " range/material out of bounds");
+        covered += me.triangle_count;
+    }
+    if (covered != s->triangle_count) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: meshes must partition the triangle list");
+    struct HostOnlyGuard { bool prev; explicit HostOnlyGuard(bool on) : prev(g_hostOnlyAlloc) { g_hostOnlyAlloc = on; } ~HostOnlyGuard() { g_hostOnlyAlloc = prev; } } guard(c->hostOnly);
+    // acceleration structure (ours)
+    rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
+    if (c->hostBvh.maxDepth + 2 > (uint32_t)(kLdsStack + kSpillStack))
+        return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: BVH depth " + std::to_string(c->hostBvh.maxDepth) + " exceeds the traversal stack");
+    HIPCHK(c, c->nodes.alloc(c->hostBvh.nodes.size() * 4)); HIPCHK(c, c->leafTris.alloc(c->hostBvh.tris.size() * 3));
+    if (upload(c, c->nodes.p, c->hostBvh.nodes.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
+    // per-triangle gather records
+    const uint32_t nT = s->triangle_count;
+    std::vector<float> pos((size_t)nT * 12), shade((size_t)nT * 16);
+    for (uint32_t i = 0; i < nT; ++i) {
+        const uint32_t* t = tri(i);
+        const fyprt_vertex &a = s->vertices[t[0]], &b = s->vertices[t[1]], &cc = s->vertices[t[2]];
+        float* p = &pos[(size_t)i * 12]; float* q = &shade[(size_t)i * 16];
+        float matBits; std::memcpy(&matBits, &t[3], 4);
+        p[0] = a.position[0]; p[1] = a.position[1]; p[2] = a.position[2]; p[3] = matBits;
+        p[4] = b.position[0]; p[5] = b.position[1]; p[6] = b.position[2]; p[7] = 0.0f;
+        p[8] = cc.position[0]; p[9] = cc.position[1]; p[10] = cc.position[2]; p[11] = 0.0f;
+        q[0] = a.normal[0]; q[1] = a.normal[1]; q[2] = a.normal[2]; q[3] = a.uv[0];
+        q[4] = b.normal[0]; q[5] = b.normal[1]; q[6] = b.normal[2]; q[7] = a.uv[1];
+        q[8] = cc.normal[0]; q[9] = cc.normal[1]; q[10] = cc.normal[2]; q[11] = b.uv[0];
+        q[12] = b.uv[1]; q[13] = cc.uv[0]; q[14] = cc.uv[1]; q[15] = matBits;
+    }
+    HIPCHK(c, c->triPos.alloc((size_t)nT * 3)); HIPCHK(c, c->triShade.alloc((size_t)nT * 4));
+    if (upload(c, c->triPos.p, pos.data(), c->triPos.bytes()) || upload(c, c->triShade.p, shade.data(), c->triShade.bytes())) return FYPRT_EHIP;
+    // materials (Material.cuh:7-16 -> 3 quads)
+    std::vector<float> mats((size_t)s->material_count * 12, 0.0f);
+    std::vector<char> emissiveMat(s->material_count, 0);
+    for (uint32_t i = 0; i < s->material_count; ++i) {
+        const fyprt_material& m = s->materials[i]; float* q = &mats[(size_t)i * 12];
+        q[0] = m.albedo[0]; q[1] = m.albedo[1]; q[2] = m.albedo[2];
+        uint32_t info = ((m.is_use_albedo_map & 0xFFu) ? 0x80000000u : 0u) | (m.albedo_map_index > 0x7FFFFFFFu ? 0x7FFFFFFFu : m.albedo_map_index);
+        std::memcpy(&q[3], &info, 4);
+        q[4] = m.roughness; q[5] = m.metallic; q[6] = m.emission_power;
+        q[8] = m.emission_color[0]; q[9] = m.emission_color[1]; q[10] = m.emission_color[2];
+        const float ex = m.emission_color[0] * m.emission_power, ey = m.emission_color[1] * m.emission_power, ez = m.emission_color[2] * m.emission_power;
+        emissiveMat[i] = ((ex * ex + ey * ey) + ez * ez) > 0.0f;       // glm::length2(GetEmission()) > 0 (Scene.cpp:216)
+    }
+    HIPCHK(c, c->mats.alloc((size_t)s->material_count * 3));
+    if (upload(c, c->mats.p, mats.data(), c->mats.bytes())) return FYPRT_EHIP;
+    // textures
+    for (auto& t : c->texPixels) t.release();
+    c->texPixels.assign(s->texture_count, DevBuf<uint32_t>());
+    std::vector<DevTexture> tt(s->texture_count);
+    for (uint32_t i = 0; i < s->texture_count; ++i) {
+        const fyprt_texture& t = s->textures[i];
+        if (!t.pixels || t.width == 0 || t.height == 0) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: empty texture");
+        HIPCHK(c, c->texPixels[i].alloc((size_t)t.width * t.height));
+        if (upload(c, c->texPixels[i].p, t.pixels, c->texPixels[i].bytes())) return FYPRT_EHIP;
+        tt[i] = DevTexture{c->texPixels[i].p, t.width, t.height, 0};
+    }
+    HIPCHK(c, c->texTable.alloc(s->texture_count));
+    if (upload(c, c->texTable.p, tt.data(), c->texTable.bytes())) return FYPRT_EHIP;
+    // emissive list (Scene::InitSceneEmissiveTriangles, Scene.cpp:209-221)
+    std::vector<uint32_t> em;
+    if (s->emissive_triangles) em.assign(s->emissive_triangles, s->emissive_triangles + s->emissive_count);
+    else for (uint32_t i = 0; i < nT; ++i) if (emissiveMat[tri(i)[3]]) em.push_back(i);
+    for (uint32_t e : em) if (e >= nT) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: emissive triangle index out of range");
+    HIPCHK(c, c->emissive.alloc(em.size()));
+    if (upload(c, c->emissive.p, em.data(), c->emissive.bytes())) return FYPRT_EHIP;
+    // light trees: prebuilt (reference shape) or ours
+    rth::LightTrees& lt = c->hostLt; lt = rth::LightTrees();
+    c->meshCount = s->mesh_count;
+    if (s->light_trees && s->light_trees->tlas_nodes) {
+        const fyprt_lighttrees& L = *s->light_trees;
+        lt.tlas.assign(L.tlas_nodes, L.tlas_nodes + L.tlas_node_count); lt.tlasRoot = L.tlas_root;
+        lt.first.assign(L.blas_first, L.blas_first + s->mesh_count); lt.count.assign(L.blas_count, L.blas_count + s->mesh_count);
+        lt.root.assign(L.blas_root, L.blas_root + s->mesh_count);
+        uint32_t total = 0; for (uint32_t m = 0; m < s->mesh_count; ++m) total = std::max(total, lt.first[m] + lt.count[m]);
+        lt.blas.assign(L.blas_nodes, L.blas_nodes + total);
+    } else {
+        rth::BuildLightTrees(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, s->materials, lt);
+    }
+    static_assert(sizeof(DevLTNode) == sizeof(fyprt_lighttree_node), "light tree node layout");
+    HIPCHK(c, c->ltTlas.alloc(lt.tlas.size())); HIPCHK(c, c->ltBlas.alloc(lt.blas.size()));
+    HIPCHK(c, c->ltFirst.alloc(s->mesh_count)); HIPCHK(c, c->ltCount.alloc(s->mesh_count)); HIPCHK(c, c->ltRoot.alloc(s->mesh_count));
+    if (upload(c, c->ltTlas.p, lt.tlas.data(), c->ltTlas.bytes()) || upload(c, c->ltBlas.p, lt.blas.data(), c->ltBlas.bytes()) ||
+        upload(c, c->ltFirst.p, lt.first.data(), c->ltFirst.bytes()) || upload(c, c->ltCount.p, lt.count.data(), c->ltCount.bytes()) ||
+        upload(c, c->ltRoot.p, lt.root.data(), c->ltRoot.bytes())) return FYPRT_EHIP;
+    DevScene& d = c->dsc;
+    d.nodes = c->nodes.p; d.leafTris = c->leafTris.p; d.rootRef = c->hostBvh.rootRef; d.triCount = nT;
+    d.triPos = c->triPos.p; d.triShade = c->triShade.p; d.mats = c->mats.p; d.textures = c->texTable.p; d.textureCount = s->texture_count;
+    d.emissive = c->emissive.p; d.emissiveCount = (uint32_t)em.size();
+    d.ltTlas = c->ltTlas.p; d.ltTlasCount = (uint32_t)lt.tlas.size(); d.ltTlasRoot = lt.tlasRoot;
+    d.ltBlas = c->ltBlas.p; d.ltFirst = c->ltFirst.p; d.ltCount = c->ltCount.p; d.ltRoot = c->ltRoot.p;
+    d.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
+    c->haveScene = true;
+    return FYPRT_OK;
+}
+
+int fyprt_set_camera(fyprt_context* c, const fyprt_camera_desc* cam) {
+    if (!c || !cam) return FYPRT_EINVAL;
+    if (cam->viewport_width == 0 || cam->viewport_height == 0) return c->fail(FYPRT_EINVAL, "fyprt_set_camera: empty viewport");
+    DevCamera& d = c->dcam;
+    std::memcpy(&d.invProj, cam->inverse_projection, 64); std::memcpy(&d.invView, cam->inverse_view, 64);
+    float pv[16]; matmul_cm(cam->prev_projection, cam->prev_view, pv);
+    std::memcpy(&d.prevProjView, pv, 64);
+    d.position = f3{cam->position[0], cam->position[1], cam->position[2]};
+    d.W = cam->viewport_width; d.H = cam->viewport_height;
+    c->haveCamera = true;
+    return FYPRT_OK;
+}
+
+static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) {
+    if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context (device -1) cannot render");
+    if (!c->haveScene || !c->haveCamera || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_render: resize, upload_scene and set_camera must precede render");
+    if (c->dcam.W != c->W || c->dcam.H != c->H) return c->fail(FYPRT_ESTATE, "fyprt_render: camera viewport differs from the render size");
+    const int tech = s->technique;
+    if (tech < 0 || tech > 8) return c->fail(FYPRT_EINVAL, "fyprt_render: unknown technique");
+    if ((tech == FYPRT_LIGHT_SOURCE_SAMPLING || tech == FYPRT_NEE) && (c->dsc.emissiveCount == 0 || c->dsc.ltTlasCount == 0))
+        return c->fail(FYPRT_ENOLIGHT, "fyprt_render: technique needs emissive triangles and a light tree");
+    if (tech == FYPRT_RESTIR_DI && c->dsc.emissiveCount == 0) return c->fail(FYPRT_ENOLIGHT, "fyprt_render: ReSTIR DI needs emissive triangles");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevSettings st;
+    st.sky = f3{s->sky_color[0], s->sky_color[1], s->sky_color[2]};
+    st.maxBounces = (uint8_t)s->light_bounces; st.sampleCount = (uint8_t)s->sample_count;       // Renderer.cu:2444, :2480-2481
+    st.candidateCount = (uint32_t)s->light_candidate_count; st.randSeed = s->rand_seed;
+    st.useTemporal = s->use_temporal_reuse ? 1u : 0u; st.useSpatial = s->use_spatial_reuse ? 1u : 0u;
+    st.historyLimit = (uint8_t)s->temporal_history_limit; st.numNeighbors = (uint8_t)s->spatial_neighbor_num; st.radius = (uint8_t)s->spatial_neighbor_radius;
+    DevFrame fr;
+    fr.accum = c->accum.p; fr.image = c->externalImage ? c->externalImage : c->image.p; fr.payload = c->payload.p; fr.depth = c->depth.p;
+    fr.normalPrev = c->normalFlip ? c->normalB.p : c->normalA.p; fr.normalCur = c->normalFlip ? c->normalA.p : c->normalB.p;
+    fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p;
+    fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
+    c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
+    if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 8, c->stream));
+    // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
+    if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
+    const uint32_t tilesX = (c->W + 15u) / 16u;
+    auto gridFor = [&](uint32_t rb, uint32_t re) { return dim3(tilesX * ((re - rb + 15u) / 16u)); };
+    const dim3 block(kBlock);
+    const dim3 grid = gridFor(c->rowBegin, c->rowEnd);
+    int ei = 0;
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+    int launches = 0;
+    switch (tech) {
+        case FYPRT_BRUTE_FORCE: hipLaunchKernelGGL(k_path<T_BRUTE>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_UNIFORM_SAMPLING: hipLaunchKernelGGL(k_path<T_UNIFORM>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_COSINE_WEIGHTED_SAMPLING: hipLaunchKernelGGL(k_path<T_COSINE>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_GGX_SAMPLING: hipLaunchKernelGGL(k_path<T_GGX>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_BRDF_SAMPLING: hipLaunchKernelGGL(k_path<T_BRDF>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_LIGHT_SOURCE_SAMPLING: hipLaunchKernelGGL(k_light_source, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_NEE: hipLaunchKernelGGL(k_nee, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_RESTIR_DI: case FYPRT_RESTIR_GI: {
+            const uint32_t p1b = (c->rowBegin > c->halo) ? c->rowBegin - c->halo : 0u;
+            const uint32_t p1e = (c->rowEnd + c->halo < c->H) ? c->rowEnd + c->halo : c->H;
+            const dim3 g1 = gridFor(p1b, p1e);
+            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
+            else hipLaunchKernelGGL(k_gi_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
+            if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
+            else hipLaunchKernelGGL(k_gi_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
+            launches = 2;
+            c->normalFlip = !c->normalFlip;
+            break;
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+    c->lastLaunches = launches;
+    if (s->to_accumulate) c->frameIndex++; else c->frameIndex = 1;       // Renderer.cu:258-261
+    return FYPRT_OK;
+}
+
+int fyprt_render(fyprt_context* c, const fyprt_settings* s, fyprt_frame_stats* stats) {
+    if (!c || !s) return FYPRT_EINVAL;
+    int rc = enqueue_frame(c, s, true);
+    if (rc != FYPRT_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                            // cudaDeviceSynchronize, Renderer.cu:237
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->launches = (uint32_t)c->lastLaunches;
+        float total = 0.0f;
+        for (int k = 0; k < c->lastLaunches; ++k) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]); stats->kernel_ms_part[k] = ms; total += ms; }
+        stats->kernel_ms = total;
+        if (c->countRays) { unsigned long long r = 0; (void)hipMemcpy(&r, c->rayCounter.p, 8, hipMemcpyDeviceToHost); stats->rays = r; }
+    }
+    return FYPRT_OK;
+}
+
+int fyprt_render_async(fyprt_context* c, const fyprt_settings* s) { if (!c || !s) return FYPRT_EINVAL; return enqueue_frame(c, s, false); }
+int fyprt_synchronize(fyprt_context* c) { if (!c) return FYPRT_EINVAL; if (c->hostOnly) return FYPRT_OK; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return FYPRT_OK; }
+
+int fyprt_readback(fyprt_context* c, uint32_t* rgba8, float* accum4) {
+    if (!c) return FYPRT_EINVAL;
+    if (c->hostOnly || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_readback before fyprt_resize");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t off = (size_t)c->rowBegin * c->W, cnt = (size_t)(c->rowEnd - c->rowBegin) * c->W;
+    const uint32_t* img = c->externalImage ? c->externalImage : c->image.p;
+    if (rgba8) HIPCHK(c, hipMemcpy(rgba8 + off, img + off, cnt * 4, hipMemcpyDeviceToHost));
+    if (accum4) HIPCHK(c, hipMemcpy(accum4 + off * 4, c->accum.p + off, cnt * 16, hipMemcpyDeviceToHost));
+    return FYPRT_OK;
+}
+
+int fyprt_image_device_ptr(fyprt_context* c, void** p) { if (!c || !p) return FYPRT_EINVAL; *p = c->externalImage ? (void*)c->externalImage : (void*)c->image.p; return FYPRT_OK; }
+int fyprt_set_external_image(fyprt_context* c, void* p) { if (!c) return FYPRT_EINVAL; c->externalImage = (uint32_t*)p; return FYPRT_OK; }
+int fyprt_stream(fyprt_context* c, void** s) { if (!c || !s) return FYPRT_EINVAL; *s = (void*)c->stream; return FYPRT_OK; }
+
+int fyprt_read_buffer(fyprt_context* c, int which, void* dst, size_t bytes) {
+    if (!c || !dst) return FYPRT_EINVAL;
+    if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context has no device buffers");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const void* src = nullptr; size_t n = 0;
+    switch (which) {
+        case FYPRT_BUF_ACCUM: src = c->accum.p; n = c->accum.bytes(); break;
+        case FYPRT_BUF_IMAGE: src = c->externalImage ? c->externalImage : c->image.p; n = c->image.bytes(); break;
+        case FYPRT_BUF_PAYLOAD: src = c->payload.p; n = c->payload.bytes(); break;
+        case FYPRT_BUF_DEPTH: src = c->depth.p; n = c->depth.bytes(); break;
+        case FYPRT_BUF_NORMAL: src = c->normalFlip ? c->normalB.p : c->normalA.p; n = c->normalA.bytes(); break;   // after the flip "prev" = frame just rendered
+        case FYPRT_BUF_DI_RESERVOIR: src = c->di.p; n = c->di.bytes(); break;
+        case FYPRT_BUF_DI_PREV: src = c->diPrev.p; n = c->diPrev.bytes(); break;
+        case FYPRT_BUF_GI_RESERVOIR: src = c->gi.p; n = c->gi.bytes(); break;
+        case FYPRT_BUF_GI_PREV: src = c->giPrev.p; n = c->giPrev.bytes(); break;
+        default: return c->fail(FYPRT_EINVAL, "fyprt_read_buffer: unknown buffer");
+    }
+    if (bytes > n) bytes = n;
+    if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return FYPRT_OK;
+}
+
+int fyprt_reset_frame_index(fyprt_context* c) { if (!c) return FYPRT_EINVAL; c->frameIndex = 1; return FYPRT_OK; }
+uint32_t fyprt_frame_index(const fyprt_context* c) { return c ? c->frameIndex : 0; }
+
+int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void* tris48, uint32_t* tri_count, int32_t* root_ref, uint32_t* max_depth) {
+    if (!c) return FYPRT_EINVAL;
+    if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_export_bvh before fyprt_upload_scene");
+    const rth::SceneBVH& b = c->hostBvh;
+    if (nodes64) std::memcpy(nodes64, b.nodes.data(), b.nodes.size() * 64);
+    if (tris48) std::memcpy(tris48, b.tris.data(), b.tris.size() * 48);
+    if (node_count) *node_count = (uint32_t)b.nodes.size();
+    if (tri_count) *tri_count = (uint32_t)b.tris.size();
+    if (root_ref) *root_ref = b.rootRef;
+    if (max_depth) *max_depth = b.maxDepth;
+    return FYPRT_OK;
+}
+
+int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32_t* tlas_count, uint32_t* tlas_root, fyprt_lighttree_node* blas,
+                            uint32_t* blas_total, uint32_t* blas_first, uint32_t* blas_count, uint32_t* blas_root) {
+    if (!c) return FYPRT_EINVAL;
+    if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_export_lighttrees before fyprt_upload_scene");
+    const rth::LightTrees& l = c->hostLt;
+    if (tlas) std::memcpy(tlas, l.tlas.data(), l.tlas.size() * sizeof(fyprt_lighttree_node));
+    if (blas) std::memcpy(blas, l.blas.data(), l.blas.size() * sizeof(fyprt_lighttree_node));
+    if (tlas_count) *tlas_count = (uint32_t)l.tlas.size();
+    if (tlas_root) *tlas_root = l.tlasRoot;
+    if (blas_total) *blas_total = (uint32_t)l.blas.size();
+    if (blas_first) std::memcpy(blas_first, l.first.data(), l.first.size() * 4);
+    if (blas_count) std::memcpy(blas_count, l.count.data(), l.count.size() * 4);
+    if (blas_root) std::memcpy(blas_root, l.root.data(), l.root.size() * 4);
+    return FYPRT_OK;
+}
+
+int fyprt_set_ray_counting(fyprt_context* c, int enabled) { if (!c) return FYPRT_EINVAL; c->countRays = enabled != 0; return FYPRT_OK; }
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// Device-side scene / frame descriptors and the traversal core (gfx950).
+//
+// HBM layout — everything a ray touches is a 16-byte-aligned quad stream:
+//   nodes     : 4 x float4 per node   (both child boxes + child refs, 64 B)
+//   leafTris  : 3 x float4 per record (v0, e1, e2, original triangle index, 48 B), leaf order
+//   triPos    : 3 x float4 per ORIGINAL triangle (p0|material, p1, p2)           — light sampling
+//   triShade  : 4 x float4 per ORIGINAL triangle (n0|uv0.x, n1|uv0.y, n2|uv1.x, uv1.y uv2.x uv2.y material)
+//   materials : 3 x float4 per material (albedo|mapinfo, roughness metallic power -, emission colour)
+// so a hit costs one dependent gather (triShade) instead of the reference's
+// triangle -> 3 vertex indices -> 3 x 32-byte vertices chain (Renderer.cu:2399-2413).
+#pragma once
+#include "rt_math.h"
+
+namespace rt {
+
+struct DevTexture { const uint32_t* pixels; uint32_t width, height, _pad; };
+
+struct DevLTNode {   // == fyprt_lighttree_node (80 B)
+    float energy; uint32_t numEmitters, left, rightOrEmitter, isLeaf; float axis[3], theta_o, theta_e; float lo[3], hi[3], centroid[3]; uint32_t _pad;
+};
+
+struct DevScene {
+    const float4* nodes; const float4* leafTris; int32_t rootRef; uint32_t triCount;
+    const float4* triPos; const float4* triShade; const float4* mats;
+    const DevTexture* textures; uint32_t textureCount;
+    const uint32_t* emissive; uint32_t emissiveCount;
+    const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
+    const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot;
+    unsigned long long* rayCounter;   // nullptr = counting off
+};
+
+struct DevCamera { m4 invProj, invView, prevProjView; f3 position; uint32_t W, H; };
+
+struct Payload { float hitDistance; float px, py, pz; float nx, ny, nz; float u, v; int32_t objectIndex; };   // Ray.h:13-22 (40 B)
+struct DIRes { uint32_t index; float W, pdf, wSum; uint32_t M; };                                             // 20 B
+struct GISample { float vp[3]; float vn[2]; float sp[3]; float sn[2]; float Lo[3]; uint32_t seed; float pdf; };
+struct GIRes { GISample s; float W; uint32_t M; float wSum; };                                                // 72 B
+static_assert(sizeof(Payload) == 40 && sizeof(DIRes) == 20 && sizeof(GIRes) == 72, "layout");
+
+struct DevFrame {
+    float4* accum; uint32_t* image; Payload* payload; float* depth; f2* normalPrev; f2* normalCur;
+    DIRes* di; DIRes* diPrev; GIRes* gi; GIRes* giPrev;
+    uint32_t W, H, frameIndex, rowBegin, rowEnd;
+};
+
+struct DevSettings {   // RenderingSettings.h:5-22 with the kernel-side uint8 casts already applied
+    f3 sky; uint32_t maxBounces, sampleCount, candidateCount, randSeed, useTemporal, useSpatial, historyLimit, numNeighbors, radius;
+};
+
+struct Hit { float t, u, v; int32_t tri; };
+
+RT_DEV f3 pos3(const Payload& p) { return mk3(p.px, p.py, p.pz); }
+RT_DEV f3 nrm3(const Payload& p) { return mk3(p.nx, p.ny, p.nz); }
+
+// ---------------------------------------------------------------------------------------------
+// Traversal stack: the first kLdsStack entries of every thread live in LDS, laid out
+// [entry][thread] so that a wave's push/pop is one conflict-free ds_write/ds_read_b32; deeper
+// entries (rare: only trees deeper than kLdsStack pending siblings) spill to scratch.
+constexpr int kLdsStack = 24;
+constexpr int kSpillStack = 56;
+constexpr int kBlock = 256;
+constexpr int32_t kExit = (int32_t)0x80000000;
+
+struct Stack {
+    int32_t* lds;                 // &shared[threadIdx.x]
+    int32_t spill[kSpillStack];
+    int top;
+    RT_DEV void push(int32_t v) { if (top < kLdsStack) lds[top * kBlock] = v; else spill[top - kLdsStack] = v; ++top; }
+    RT_DEV int32_t pop() { --top; return (top < kLdsStack) ? lds[top * kBlock] : spill[top - kLdsStack]; }
+};
+
+RT_DEV float safe_inv(float d) { return 1.0f / ((__builtin_fabsf(d) < 1e-30f) ? __builtin_copysignf(1e-30f, d) : d); }
+
+// Closest hit over the two-level BVH.  Ordered traversal (near child first, far child pushed),
+// boxes culled against closest * 1.000001f; the ray / triangle test is Möller–Trumbore with
+// exactly the reference's operation order (Renderer.cu:513-537) on (v0, e1 = v1-v0, e2 = v2-v0),
+// accepting t > 1e-4 && t < closest, no back-face culling.
+RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
+    Hit h; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.tri = -1;
+    if (sc.rayCounter) {
+        unsigned long long m = __ballot(1);
+        if ((__lane_id() == (unsigned)__builtin_ctzll(m))) atomicAdd(sc.rayCounter, (unsigned long long)__popcll(m));
+    }
+    if (sc.triCount == 0) return h;
+    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    float closestInfl = h.t * 1.000001f;
+    Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
+    int32_t cur = sc.rootRef;
+    while (true) {
+        while (cur >= 0) {
+            const float4* n = sc.nodes + (size_t)cur * 4;
+            const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
+            float ax = (q0.x - o.x) * ix, bx = (q0.w - o.x) * ix;
+            float ay = (q0.y - o.y) * iy, by = (q1.x - o.y) * iy;
+            float az = (q0.z - o.z) * iz, bz = (q1.y - o.z) * iz;
+            const float n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+            const float f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), closestInfl));
+            ax = (q1.z - o.x) * ix; bx = (q2.y - o.x) * ix;
+            ay = (q1.w - o.y) * iy; by = (q2.z - o.y) * iy;
+            az = (q2.x - o.z) * iz; bz = (q2.w - o.z) * iz;
+            const float n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), closestInfl));
+            const bool h0 = n0 <= f0, h1 = n1 <= f1;
+            const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                const bool swap = n1 < n0;
+                st.push(swap ? c0 : c1);
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else cur = st.pop();
+        }
+        if (cur == kExit) break;
+        const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+            const f3 hh = cross(d, e2);
+            const float det = dot(e1, hh), f = 1.0f / det;
+            const f3 s = o - v0;
+            const float u = f * dot(s, hh);
+            if (u < 0.0f || u > 1.0f) continue;
+            const f3 q = cross(s, e1);
+            const float v = f * dot(d, q);
+            if (v < 0.0f || (u + v) > 1.0f) continue;
+            const float t = f * dot(e2, q);
+            if (t > 0.0001f && t < h.t) { h.t = t; h.u = u; h.v = v; h.tri = __float_as_int(c.y); closestInfl = t * 1.000001f; }
+        }
+        cur = st.pop();
+    }
+    return h;
+}
+
+// Miss (Renderer.cu:2423-2429; worldPosition / objectIndex zero-filled / -1: DESIGN.md §5 R1)
+RT_DEV Payload make_miss() { Payload p; p.hitDistance = -1.0f; p.px = p.py = p.pz = 0.0f; p.nx = p.ny = p.nz = 0.0f; p.u = 0.0f; p.v = 0.0f; p.objectIndex = -1; return p; }
+// ClosestHit (Renderer.cu:2389-2421) from the per-triangle shading record
+RT_DEV Payload make_hit(const DevScene& sc, f3 o, f3 d, const Hit& h) {
+    const float4* s = sc.triShade + (size_t)h.tri * 4;
+    const float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+    Payload p; p.hitDistance = h.t; p.objectIndex = h.tri;
+    const f3 pos = o + d * h.t;
+    p.px = pos.x; p.py = pos.y; p.pz = pos.z;
+    const float w = (1.0f - h.u) - h.v;
+    const f3 n = normalize((mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * h.u) + mk3(s2.x, s2.y, s2.z) * h.v);
+    p.nx = n.x; p.ny = n.y; p.nz = n.z;
+    p.u = (s0.w * w + s2.w * h.u) + s3.y * h.v;      // uv0.x, uv1.x, uv2.x
+    p.v = (s1.w * w + s3.x * h.u) + s3.z * h.v;      // uv0.y, uv1.y, uv2.y
+    return p;
+}
+RT_DEV Payload trace_ray(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
+    const Hit h = trace_closest(sc, o, d, ldsBase);
+    return (h.tri < 0) ? make_miss() : make_hit(sc, o, d, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Mat { f3 albedo; uint32_t useMap, mapIndex; float roughness, metallic, power; f3 emColor; };
+RT_DEV Mat load_mat(const DevScene& sc, int idx) {
+    const float4* m = sc.mats + (size_t)idx * 3;
+    const float4 a = m[0], b = m[1], c = m[2];
+    Mat r; r.albedo = mk3(a.x, a.y, a.z);
+    const uint32_t info = (uint32_t)__float_as_int(a.w); r.useMap = info >> 31; r.mapIndex = info & 0x7FFFFFFFu;
+    r.roughness = b.x; r.metallic = b.y; r.power = b.z; r.emColor = mk3(c.x, c.y, c.z);
+    return r;
+}
+RT_DEV int tri_material(const DevScene& sc, int tri) { return __float_as_int(sc.triShade[(size_t)tri * 4 + 3].w); }
+RT_DEV f3 emission(const Mat& m) { return m.emColor * m.power; }                   // Material.cu:5-8
+
+// Texture::SampleBilinear (Texture.cu:103-139) -> RGBA8 re-quantised -> unpacked by the caller
+RT_DEV f3 sample_albedo(const DevScene& sc, const Mat& m, float u, float v) {
+    if (m.useMap && m.mapIndex < sc.textureCount) {
+        const DevTexture t = sc.textures[m.mapIndex];
+        u = (u < 0.0f) ? 0.0f : (u > 1.0f ? 1.0f : u);
+        v = (v < 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
+        const float x = u * (float)(t.width - 1), y = v * (float)(t.height - 1);
+        const int x0 = (int)x, y0 = (int)y;
+        const int x1 = (x0 + 1 < (int)t.width) ? x0 + 1 : x0, y1 = (y0 + 1 < (int)t.height) ? y0 + 1 : y0;
+        const float tx = x - (float)x0, ty = y - (float)y0;
+        const f4 c00 = unpack_abgr(t.pixels[y0 * t.width + x0]), c10 = unpack_abgr(t.pixels[y0 * t.width + x1]);
+        const f4 c01 = unpack_abgr(t.pixels[y1 * t.width + x0]), c11 = unpack_abgr(t.pixels[y1 * t.width + x1]);
+        const f4 cx0 = c00 * (1.0f - tx) + c10 * tx, cx1 = c01 * (1.0f - tx) + c11 * tx;
+        const f4 c = unpack_abgr(pack_abgr(cx0 * (1.0f - ty) + cx1 * ty));
+        return mk3(c.x, c.y, c.z);
+    }
+    return m.albedo;
+}
+
+// Camera::RecalculateRayDirections (Camera.cpp:136-153) for one pixel
+RT_DEV f3 ray_direction(const DevCamera& cam, uint32_t x, uint32_t y) {
+    const float cx = ((float)x / (float)cam.W) * 2.0f - 1.0f, cy = ((float)y / (float)cam.H) * 2.0f - 1.0f;
+    const f4 target = mul(cam.invProj, mk4(cx, cy, 1.0f, 1.0f));
+    const f3 dl = normalize(mk3(target.x, target.y, target.z) / target.w);
+    const f4 w = mul(cam.invView, mk4(dl.x, dl.y, dl.z, 0.0f));
+    return mk3(w.x, w.y, w.z);
+}
+
+// Triangle helpers (Triangle.cuh:14-59) on a triPos record
+struct TriGeom { f3 p0, p1, p2, n0, n1, n2; int mat; };
+RT_DEV TriGeom load_tri(const DevScene& sc, uint32_t tri) {
+    const float4* p = sc.triPos + (size_t)tri * 3; const float4* s = sc.triShade + (size_t)tri * 4;
+    const float4 a = p[0], b = p[1], c = p[2], s0 = s[0], s1 = s[1], s2 = s[2];
+    TriGeom g; g.p0 = mk3(a.x, a.y, a.z); g.p1 = mk3(b.x, b.y, b.z); g.p2 = mk3(c.x, c.y, c.z);
+    g.n0 = mk3(s0.x, s0.y, s0.z); g.n1 = mk3(s1.x, s1.y, s1.z); g.n2 = mk3(s2.x, s2.y, s2.z); g.mat = __float_as_int(a.w);
+    return g;
+}
+RT_DEV f3 tri_centroid(const TriGeom& g) { return ((g.p0 + g.p1) + g.p2) / 3.0f; }
+RT_DEV f3 tri_normal(const TriGeom& g) { return normalize(((g.n0 + g.n1) + g.n2) / 3.0f); }
+RT_DEV float tri_area(const TriGeom& g) { return 0.5f * length(cross(g.p1 - g.p0, g.p2 - g.p0)); }
+RT_DEV f3 tri_random_point(const TriGeom& g, uint32_t& seed) {
+    const float r1 = rnd(seed), r2 = rnd(seed), s = __builtin_sqrtf(r1);
+    const float u = 1.0f - s, v = (1.0f - r2) * s, w = r2 * s;
+    return (u * g.p0 + v * g.p1) + w * g.p2;
+}
+
+}  // namespace rt

@@ -1,0 +1,583 @@
+// Per-pixel techniques (the reference's nine sampling techniques) as gfx950 kernels.
+// Each kernel cites the reference function it computes; the arithmetic order is the
+// reference's (Renderer.cu:565-2387), the execution structure is ours: one wave covers an
+// 8x8 pixel tile (coherent primary rays), 4 waves per workgroup, traversal stack in LDS,
+// scene read through the quad streams of rt_device.h, accumulation / tonemap / pack fused.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+enum Tech { T_BRUTE = 0, T_UNIFORM = 1, T_COSINE = 2, T_GGX = 3, T_BRDF = 4, T_LIGHT = 5, T_NEE = 6, T_DI = 7, T_GI = 8 };
+
+// pixel owned by this thread: workgroup = 16x16 pixels, wave = 8x8 tile
+RT_DEV bool pixel_of_thread(const DevFrame& fr, uint32_t rowBegin, uint32_t rowEnd, uint32_t& x, uint32_t& y) {
+    const uint32_t tilesX = (fr.W + 15u) >> 4;
+    const uint32_t bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    x = (bx << 4) + ((wave & 1u) << 3) + (lane & 7u);
+    y = rowBegin + (by << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    return x < fr.W && y < rowEnd;
+}
+
+// Common epilogue of all 11 reference kernels (e.g. Renderer.cu:2448-2465)
+RT_DEV void epilogue(const DevFrame& fr, uint32_t i, f4 c) {
+    if (!(finitef(c.x) && finitef(c.y) && finitef(c.z) && finitef(c.w))) c = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 a4 = fr.accum[i];
+    f4 a = mk4(a4.x + c.x, a4.y + c.y, a4.z + c.z, a4.w + c.w);
+    fr.accum[i] = make_float4(a.x, a.y, a.z, a.w);
+    const float fi = (float)fr.frameIndex;
+    a = mk4(a.x / fi, a.y / fi, a.z / fi, a.w / fi);
+    a = mk4(a.x / (a.x + 1.0f), a.y / (a.y + 1.0f), a.z / (a.z + 1.0f), a.w / (a.w + 0.0f));
+    a = mk4(gclamp(a.x, 0.0f, 1.0f), gclamp(a.y, 0.0f, 1.0f), gclamp(a.z, 0.0f, 1.0f), gclamp(a.w, 0.0f, 1.0f));
+    fr.image[i] = pack_abgr(a);
+}
+RT_DEV f4 rgb1(f3 c) { return mk4(c.x, c.y, c.z, 1.0f); }
+
+// ============================================================ techniques 0-4 (Renderer.cu:565-1284)
+template <int TECH>
+RT_DEV f3 sample_dir(f3 n, f3 V, const Mat& m, f3 albedo, float ggxRoughness, uint32_t& seed, float& pdf) {
+    if (TECH == T_BRUTE || TECH == T_UNIFORM) { pdf = pdf_uniform(); return sample_uniform(n, seed); }
+    if (TECH == T_COSINE) { pdf = -1.0f; return sample_cosine(n, seed); }
+    if (TECH == T_GGX) return sample_ggx(n, V, ggxRoughness, seed, pdf);
+    return sample_brdf(n, V, albedo, m.metallic, m.roughness, seed, pdf);
+}
+
+template <int TECH>
+__global__ __launch_bounds__(kBlock) void k_path(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    uint32_t seed = i * fr.frameIndex;
+    const f3 pd = ray_direction(cam, x, y);
+    const Payload pp = trace_ray(sc, cam.position, pd, stk);
+    if (pp.hitDistance < 0.0f) { epilogue(fr, i, rgb1(st.sky)); return; }
+    const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+    if (length(emission(hm)) > 0.0f) { epilogue(fr, i, rgb1(emission(hm))); return; }
+    f3 radiance = splat3(0.0f);
+    const int nSamples = (TECH == T_BRUTE) ? 1 : (int)st.sampleCount;
+    const f3 palbedo = sample_albedo(sc, hm, pp.u, pp.v);
+    for (int s = 0; s < nSamples; ++s) {
+        if (TECH != T_BRUTE) seed += (uint32_t)((s + 1) * 27);
+        float pdf;
+        f3 dir = sample_dir<TECH>(nrm3(pp), -pd, hm, palbedo, hm.roughness, seed, pdf);
+        f3 brdf = eval_brdf(nrm3(pp), -pd, dir, palbedo, hm.metallic, hm.roughness);
+        float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
+        if (TECH == T_COSINE) pdf = pdf_cosine(cosT);
+        f3 T = splat3(1.0f) * ((brdf * cosT) / pdf);
+        f3 ro = pos3(pp) + nrm3(pp) * 1e-12f, rd = dir;
+        for (int b = 0; b < (int)st.maxBounces; ++b) {
+            seed += (uint32_t)(((TECH == T_BRUTE) ? 0 : s) + 31 * b);
+            const Payload hit = trace_ray(sc, ro, rd, stk);
+            if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; break; }
+            const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
+            const f3 em = emission(m);
+            if (length(em) > 0.0f) { radiance = radiance + T * em; break; }
+            const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
+            float bpdf;
+            const f3 bdir = sample_dir<TECH>(nrm3(hit), -rd, m, alb, hm.roughness /* primary roughness, Renderer.cu:1091-1092 */, seed, bpdf);
+            const f3 bbrdf = eval_brdf(nrm3(hit), -rd, bdir, alb, m.metallic, m.roughness);
+            const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
+            if (TECH == T_COSINE) bpdf = pdf_cosine(bcos);
+            T = T * ((bbrdf * bcos) / bpdf);
+            ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
+        }
+    }
+    if (TECH != T_BRUTE) radiance = radiance / (float)st.sampleCount;
+    epilogue(fr, i, rgb1(radiance));
+}
+
+// ============================================================ light tree (LightTree.cuh:91-117, LightTree.cu, ConeBounds.cuh:47-87)
+RT_DEV float cone_theta_to_box(const DevLTNode& c, f3 p) {
+    const f3 axis = normalize(mk3(c.centroid[0], c.centroid[1], c.centroid[2]) - p);
+    float maxTheta = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f3 corner = mk3((k & 4) ? c.hi[0] : c.lo[0], (k & 2) ? c.hi[1] : c.lo[1], (k & 1) ? c.hi[2] : c.lo[2]);
+        const f3 dir = normalize(corner - p);
+        maxTheta = __builtin_fmaxf(maxTheta, acos_f(gclamp(dot(axis, dir), -1.0f, 1.0f)));
+    }
+    return maxTheta;
+}
+RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
+    const float theta_u = cone_theta_to_box(c, spPos);
+    f3 dir = spPos - mk3(c.centroid[0], c.centroid[1], c.centroid[2]);
+    const float d2 = __builtin_fmaxf(dot(dir, dir), 1e-12f);
+    dir = normalize(dir);
+    const float dotVal = gclamp(dot(mk3(c.axis[0], c.axis[1], c.axis[2]), dir), -1.0f, 1.0f);
+    const float theta = acos_f(dotVal);
+    const float angleTerm = gclamp((theta - c.theta_o) - theta_u, 0.0f, c.theta_e);
+    return (c.energy * cos_f(angleTerm)) / d2;
+}
+RT_DEV uint32_t lt_descend(const DevLTNode* nodes, uint32_t idx, f3 spPos, float& r, float& pmf) {
+    const uint32_t l = nodes[idx].left, rt_ = nodes[idx].rightOrEmitter;
+    float Il = cluster_importance(spPos, nodes[l]);
+    const float Ir = cluster_importance(spPos, nodes[rt_]);
+    float sum = Il + Ir;
+    if (!(sum > 0.0f) || (Il + Ir) <= 0.0f) { sum = 1.0f; Il = 0.5f; }
+    const float pl = gclamp(Il / sum, 1e-6f, 1.0f - 1e-6f);
+    if (r < pl) { pmf *= pl; r = r / pl; return l; }
+    const float pr = 1.0f - pl; pmf *= pr; r = (r - pl) / pr; return rt_;
+}
+struct PickedLight { uint32_t tri; float pmf; };
+RT_DEV PickedLight pick_light(const DevScene& sc, f3 spPos, uint32_t& seed) {      // PickLight_TLAS + PickLight_BLAS
+    PickedLight out; out.tri = ~0u; out.pmf = 0.0f;
+    float r = rnd(seed);
+    if (sc.ltTlasCount == 0 || sc.ltTlasRoot == ~0u) return out;
+    uint32_t idx = sc.ltTlasRoot; float pmfT = 1.0f;
+    r = gclamp(r, 0.0f, 0.9999999f);
+    while (!sc.ltTlas[idx].isLeaf) idx = lt_descend(sc.ltTlas, idx, spPos, r, pmfT);
+    const uint32_t mesh = sc.ltTlas[idx].rightOrEmitter;
+    if (sc.ltCount[mesh] == 0 || sc.ltRoot[mesh] == ~0u) return out;
+    const DevLTNode* b = sc.ltBlas + sc.ltFirst[mesh];
+    uint32_t bi = sc.ltRoot[mesh]; float pmfB = 1.0f;
+    r = gclamp(r, 0.0f, 0.9999999f);
+    while (!b[bi].isLeaf) bi = lt_descend(b, bi, spPos, r, pmfB);
+    out.tri = b[bi].rightOrEmitter; out.pmf = pmfT * pmfB;
+    return out;
+}
+RT_DEV float direct_emitter_pmf(const DevScene& sc, f3 spPos, uint32_t emitterTri) {   // ComputeDirectEmitterPMF, LightTree.cu:156-276
+    if (sc.ltTlasCount == 0 || sc.ltTlasRoot == ~0u) return 0.0f;
+    uint32_t tlasLeaf = ~0u;
+    for (uint32_t i = 0; i < sc.ltTlasCount && tlasLeaf == ~0u; ++i) {
+        if (!sc.ltTlas[i].isLeaf) continue;
+        const uint32_t mesh = sc.ltTlas[i].rightOrEmitter;
+        const DevLTNode* b = sc.ltBlas + sc.ltFirst[mesh];
+        for (uint32_t j = 0; j < sc.ltCount[mesh]; ++j)
+            if (b[j].isLeaf && b[j].rightOrEmitter == emitterTri) { tlasLeaf = i; break; }
+    }
+    if (tlasLeaf == ~0u) return 0.0f;
+    float pmf = 1.0f; uint32_t idx = sc.ltTlasRoot;
+    const DevLTNode* nodes = sc.ltTlas; uint32_t target = tlasLeaf;
+    for (int level = 0; level < 2; ++level) {
+        while (!nodes[idx].isLeaf) {                              // index-range heuristic (:227, :263), bug-for-bug
+            const uint32_t l = nodes[idx].left, r = nodes[idx].rightOrEmitter;
+            float Il = cluster_importance(spPos, nodes[l]);
+            const float Ir = cluster_importance(spPos, nodes[r]);
+            float sum = Il + Ir;
+            if (!(sum > 0.0f)) { Il = 0.5f; sum = 1.0f; }
+            const float pl = Il / sum;
+            if (l <= target && target <= l + (nodes[l].numEmitters - 1u)) { pmf *= pl; idx = l; }
+            else { pmf *= (1.0f - pl); idx = r; }
+        }
+        if (level == 0) {
+            const uint32_t mesh = nodes[idx].rightOrEmitter;
+            if (sc.ltCount[mesh] == 0) return 0.0f;
+            nodes = sc.ltBlas + sc.ltFirst[mesh]; idx = sc.ltRoot[mesh]; target = emitterTri;
+        }
+    }
+    return pmf;
+}
+
+// ============================================================ LIGHT_SOURCE_SAMPLING (Renderer.cu:1287-1408)
+__global__ __launch_bounds__(kBlock) void k_light_source(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    uint32_t seed = i * fr.frameIndex;
+    const f3 pd = ray_direction(cam, x, y);
+    const Payload pp = trace_ray(sc, cam.position, pd, stk);
+    if (pp.hitDistance < 0.0f) { epilogue(fr, i, rgb1(st.sky)); return; }
+    const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+    if (length(emission(hm)) > 0.0f) { epilogue(fr, i, rgb1(emission(hm))); return; }
+    f3 radiance = splat3(0.0f);
+    const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+    for (int s = 0; s < (int)st.sampleCount; ++s) {
+        seed += (uint32_t)((s + 1) * 27);
+        const PickedLight pl = pick_light(sc, pos3(pp), seed);
+        const TriGeom g = load_tri(sc, pl.tri);
+        const f3 ep = tri_random_point(g, seed);
+        f3 dir = ep - pos3(pp);
+        const float dist = length(pos3(pp) - ep);
+        dir = dir / dist;
+        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+        const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
+        const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
+        const float triAreaPDF = 1.0f / tri_area(g);
+        const float totalPDF = (pl.pmf * triAreaPDF) * (dist * dist);
+        const f3 T = splat3(1.0f) * (((brdf * cx) * cy) / totalPDF);
+        const Payload hit = trace_ray(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, stk);
+        if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; continue; }
+        if ((uint32_t)hit.objectIndex != pl.tri) continue;
+        const Mat lm = load_mat(sc, g.mat);
+        if (length(emission(lm)) > 0.0f) radiance = radiance + T * emission(lm);
+    }
+    radiance = radiance / (float)st.sampleCount;
+    epilogue(fr, i, rgb1(radiance));
+}
+
+// ============================================================ NEE (Renderer.cu:1411-1626)
+__global__ __launch_bounds__(kBlock) void k_nee(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    uint32_t seed = i * fr.frameIndex;
+    const f3 pd = ray_direction(cam, x, y);
+    const Payload pp = trace_ray(sc, cam.position, pd, stk);
+    if (pp.hitDistance < 0.0f) { epilogue(fr, i, rgb1(st.sky)); return; }
+    {
+        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        if (length(emission(hm)) > 0.0f) { epilogue(fr, i, rgb1(emission(hm))); return; }
+    }
+    f3 radiance = splat3(0.0f);
+    const uint32_t maxBounces = st.maxBounces;
+    for (int s = 0; s < (int)st.sampleCount; ++s) {
+        seed += (uint32_t)((s + 1) * 31);
+        f3 T = splat3(1.0f), rd = pd;
+        Payload hit = pp;
+        float pdfBRDF = 1.0f, pdfDirect = 1.0f;
+        for (uint32_t bounce = 0; bounce < maxBounces; ++bounce) {
+            const Mat mat = load_mat(sc, tri_material(sc, hit.objectIndex));
+            const f3 albedo = sample_albedo(sc, mat, hit.u, hit.v);
+            const PickedLight pl = pick_light(sc, pos3(hit), seed);
+            const TriGeom g = load_tri(sc, pl.tri);
+            const f3 lp = tri_random_point(g, seed);
+            f3 ld = lp - pos3(hit);
+            const float dist = length(ld);
+            ld = ld / dist;
+            const Payload sh = trace_ray(sc, pos3(hit) + nrm3(hit) * 1e-12f, ld, stk);
+            if (sh.hitDistance > 0.0f && (uint32_t)sh.objectIndex == pl.tri) {
+                const f3 brdf = eval_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
+                const float cx = gmax(dot(ld, nrm3(hit)), 0.0f);
+                const float cy = gmax(dot(-ld, tri_normal(g)), 1e-12f);
+                const float triAreaPDF = 1.0f / tri_area(g);
+                const float lsa = (triAreaPDF * (dist * dist)) / cy;
+                pdfDirect = pl.pmf * lsa;
+                pdfBRDF = pdf_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
+                const f3 em = emission(load_mat(sc, g.mat));
+                if (maxBounces == 1) { radiance = radiance + (((T * brdf) * cx) * em) / pdfDirect; break; }
+                const float wD = pdfDirect / gmax(pdfBRDF + pdfDirect, 1e-12f);
+                radiance = radiance + ((((wD * T) * brdf) * cx) * em) / pdfDirect;
+            }
+            if (maxBounces == 1) break;
+            const f3 nd = sample_brdf(nrm3(hit), -rd, albedo, mat.metallic, mat.roughness, seed, pdfBRDF);
+            pdfBRDF = gmax(pdfBRDF, 1e-12f);
+            const f3 brdf = eval_brdf(nrm3(hit), -rd, nd, albedo, mat.metallic, mat.roughness);
+            const float cosT = dot(nd, nrm3(hit));
+            T = T * ((brdf * cosT) / pdfBRDF);
+            const f3 ro = pos3(hit) + nrm3(hit) * 1e-12f;
+            rd = nd;
+            hit = trace_ray(sc, ro, rd, stk);
+            if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; break; }
+            const Mat em = load_mat(sc, tri_material(sc, hit.objectIndex));
+            if (length(emission(em)) > 0.0f) {
+                const TriGeom eg = load_tri(sc, (uint32_t)hit.objectIndex);
+                const f3 lp2 = tri_random_point(eg, seed);
+                f3 ld2 = lp2 - pos3(hit);
+                const float dist2 = length(ld2);
+                ld2 = ld2 / dist2;
+                const float cy = gmax(dot(-ld2, tri_normal(eg)), 1e-12f);
+                const float triAreaPDF = 1.0f / tri_area(eg);
+                const float lsa = (triAreaPDF * (dist2 * dist2)) / cy;
+                pdfDirect = direct_emitter_pmf(sc, pos3(hit), (uint32_t)hit.objectIndex) * lsa;
+                const float wB = pdfBRDF / gmax(pdfBRDF + pdfDirect, 1e-12f);
+                radiance = radiance + (wB * T) * emission(em);
+                break;
+            }
+        }
+    }
+    epilogue(fr, i, rgb1(radiance / (float)st.sampleCount));
+}
+
+// ============================================================ ReSTIR DI (Renderer.cu:1628-2041)
+RT_DEV bool di_update(DIRes& r, uint32_t cand, float w, uint32_t count, float pdf, uint32_t& seed) {   // ReSTIR_DI_Reservoir.cu:3-36
+    r.wSum += w; r.M += count;
+    if (rnd(seed) < w / r.wSum) { r.index = cand; r.pdf = pdf; return true; }
+    return false;
+}
+RT_DEV DIRes di_empty() { DIRes r; r.index = 0; r.W = 0.0f; r.pdf = 0.0f; r.wSum = 0.0f; r.M = 0; return r; }
+// unshadowed target at the light centroid (Renderer.cu:1680-1730, :1799-1849)
+RT_DEV float di_target(const DevScene& sc, uint32_t emissiveSlot, const Payload& pp, f3 pd, const Mat& hm, f3 albedo) {
+    const TriGeom g = load_tri(sc, sc.emissive[emissiveSlot]);
+    const f3 ep = tri_centroid(g);
+    f3 dir = ep - pos3(pp);
+    const float dist = length(pos3(pp) - ep);
+    dir = dir / dist;
+    const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+    const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
+    const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
+    const float triAreaPDF = 1.0f / tri_area(g);
+    const float sa = triAreaPDF * (dist * dist);
+    const f3 Lr = (((brdf * cx) * cy) / sa) * emission(load_mat(sc, g.mat));
+    return length(Lr);
+}
+RT_DEV int f2i_sat(float f) { if (!(f == f)) return 0; if (f >= 2147483520.0f) return 2147483647; if (f <= -2147483648.0f) return (-2147483647 - 1); return (int)f; }
+RT_DEV uint32_t prev_pixel(const DevCamera& cam, f3 wp) {                                   // Renderer.cu:1750-1763
+    const f4 clip = mul(cam.prevProjView, mk4(wp.x, wp.y, wp.z, 1.0f));
+    float nx = 0.0f, ny = 0.0f;
+    if (clip.w != 0.0f) { nx = clip.x / clip.w; ny = clip.y / clip.w; }
+    const float sx = (nx * 0.5f + 0.5f) * (float)cam.W, sy = (ny * 0.5f + 0.5f) * (float)cam.H;
+    int px = f2i_sat(__builtin_floorf(sx)), py = f2i_sat(__builtin_floorf(sy));
+    px = px < 0 ? 0 : (px > (int)cam.W - 1 ? (int)cam.W - 1 : px);
+    py = py < 0 ? 0 : (py > (int)cam.H - 1 ? (int)cam.H - 1 : py);
+    return (uint32_t)py * cam.W + (uint32_t)px;
+}
+RT_DEV uint32_t neighbor_index(const DevCamera& cam, uint32_t W, uint32_t x, uint32_t y, uint32_t radius, uint32_t& seed) {   // :1915-1922
+    float ox = 2.0f * rnd(seed) - 1.0f, oy = 2.0f * rnd(seed) - 1.0f;
+    ox = (float)(uint32_t)(x + (uint32_t)(int)(ox * (float)radius));
+    oy = (float)(uint32_t)(y + (uint32_t)(int)(oy * (float)radius));
+    ox = __builtin_fmaxf(0.0f, __builtin_fminf((float)cam.W - 1.0f, ox));
+    oy = __builtin_fmaxf(0.0f, __builtin_fminf((float)cam.H - 1.0f, oy));
+    return (uint32_t)ox + (uint32_t)oy * W;
+}
+
+// Part 1 rows: [p1Begin, p1End) (band + halo); finished pixels (sky / emitter) go through the
+// epilogue only inside the band proper so halo rows never touch accumulation.
+__global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, p1Begin, p1End, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
+    uint32_t seed = i * (fr.frameIndex + 1u + st.randSeed);
+    const f3 pd = ray_direction(cam, x, y);
+    const Payload pp = trace_ray(sc, cam.position, pd, stk);
+    fr.payload[i] = pp;
+    fr.normalCur[i] = oct_encode(nrm3(pp));
+    DIRes R = di_empty();
+    bool finished = false; f3 finalColor = splat3(0.0f);
+    Mat hm;
+    if (pp.hitDistance < 0.0f) { finished = true; finalColor = st.sky; }
+    else {
+        hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        if (length(emission(hm)) > 0.0f) { finished = true; finalColor = emission(hm); }
+    }
+    if (finished) {
+        fr.di[i] = R;
+        fr.depth[i] = pp.hitDistance;
+        if (inBand) epilogue(fr, i, rgb1(finalColor));
+        return;
+    }
+    const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+    const uint32_t nE = sc.emissiveCount;
+    for (uint32_t k = 0; k < st.candidateCount; ++k) {
+        const uint32_t e = (uint32_t)__builtin_roundf((float)(nE - 1u) * rnd(seed));
+        const float pdf = di_target(sc, e, pp, pd, hm, albedo);
+        di_update(R, e, pdf * (float)nE, 1u, pdf, seed);
+    }
+    R.W = R.pdf > 0.0f ? ((1.0f / R.pdf) * R.wSum) / (float)R.M : 0.0f;
+    if (st.useTemporal) {
+        const uint32_t prevIdx = prev_pixel(cam, pos3(pp));
+        const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
+        DIRes prev = fr.diPrev[prevIdx];
+        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99;
+        if (valid && prev.M > 0u) {
+            const uint32_t lim = st.historyLimit * R.M;
+            prev.M = (lim < prev.M) ? lim : prev.M;
+            DIRes Tm = di_empty(); uint32_t Z = 0;
+            { const float pdf = R.pdf; di_update(Tm, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
+            const float pdf = di_target(sc, prev.index, pp, pd, hm, albedo);
+            di_update(Tm, prev.index, (pdf * prev.W) * (float)prev.M, prev.M, pdf, seed);
+            Z += pdf > 0.0f ? prev.M : 0u;
+            const float m = 1.0f / (float)Z;
+            Tm.W = Tm.pdf > 0.0f ? (1.0f / Tm.pdf) * (m * Tm.wSum) : 0.0f;
+            R = Tm;
+        }
+    }
+    fr.di[i] = R;
+    if (inBand) fr.image[i] = 0u;     // sentinel: ConvertToRGBA(vec4(0)) (Renderer.cu:2746-2750)
+}
+
+__global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    if (fr.image[i] != 0u) return;                                   // Renderer.cu:2787
+    uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
+    DIRes R = fr.di[i];
+    const Payload pp = fr.payload[i];
+    const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+    const f3 pd = ray_direction(cam, x, y);
+    if (st.useSpatial) {
+        uint32_t Z = 0; DIRes S = di_empty();
+        { const float pdf = R.pdf; di_update(S, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
+        for (uint32_t n = 0; n < st.numNeighbors; ++n) {
+            const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+            const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
+            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906) continue;
+            const DIRes N = fr.di[ni];
+            const float pdf = N.pdf;
+            di_update(S, N.index, (pdf * N.W) * (float)N.M, N.M, pdf, seed);
+            Z += pdf > 0.0f ? N.M : 0u;
+        }
+        const float m = 1.0f / (float)Z;
+        S.W = S.pdf > 0.0f ? (1.0f / S.pdf) * (m * S.wSum) : 0.0f;
+        R = S;
+    }
+    const uint32_t ti = sc.emissive[R.index];
+    const TriGeom g = load_tri(sc, ti);
+    const f3 ep = tri_random_point(g, seed);
+    f3 dir = ep - pos3(pp);
+    const float dist = length(pos3(pp) - ep);
+    dir = dir / dist;
+    const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+    const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+    const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
+    const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
+    const float triAreaPDF = 1.0f / tri_area(g);
+    const float sa = triAreaPDF * (dist * dist);
+    const f3 T = ((brdf * cx) * cy) / sa;
+    const Payload hit = trace_ray(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, stk);
+    f3 radiance = splat3(0.0f);
+    if ((uint32_t)hit.objectIndex == ti && hit.hitDistance >= 0.0f) {
+        const Mat lm = load_mat(sc, g.mat);
+        if (length(emission(lm)) > 0.0f) { radiance = T * emission(lm); radiance = radiance * R.W; }
+    } else if (hit.hitDistance < 0.0f) radiance = T * st.sky;
+    fr.depth[i] = pp.hitDistance;
+    fr.diPrev[i] = R;
+    epilogue(fr, i, rgb1(radiance));
+}
+
+// ============================================================ ReSTIR GI (Renderer.cu:2043-2387)
+RT_DEV void gi_reset_sample(GISample& s) { s.vp[0] = s.vp[1] = s.vp[2] = 0.0f; s.vn[0] = s.vn[1] = 0.0f; s.sp[0] = s.sp[1] = s.sp[2] = 0.0f; s.sn[0] = s.sn[1] = 0.0f; s.Lo[0] = s.Lo[1] = s.Lo[2] = 0.0f; s.seed = 0; s.pdf = 0.0f; }
+RT_DEV void gi_reset(GIRes& r) { gi_reset_sample(r.s); r.W = 0.0f; r.M = 0; r.wSum = 0.0f; }
+RT_DEV bool gi_update(GIRes& r, const GISample& s, float w, uint32_t count, float pdf, uint32_t& seed) {   // ReSTIR_GI_Reservoir.cu:5-34
+    r.wSum += w; r.M += count;
+    if (rnd(seed) < w / r.wSum) { r.s = s; r.s.pdf = pdf; return true; }
+    return false;
+}
+RT_DEV void gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {                                // :36-43
+    const uint32_t prev = r.M;
+    gi_update(r, o.s, (pdf * o.wSum) * (float)o.M, 1u, pdf, seed);
+    r.M = prev + o.M;
+}
+RT_DEV f3 lo3(const GISample& s) { return mk3(s.Lo[0], s.Lo[1], s.Lo[2]); }
+
+__global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, p1Begin, p1End, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
+    uint32_t seed = i * (fr.frameIndex + 1u + st.randSeed);
+    const f3 pd = ray_direction(cam, x, y);
+    const Payload pp = trace_ray(sc, cam.position, pd, stk);
+    fr.payload[i] = pp;
+    fr.normalCur[i] = oct_encode(nrm3(pp));
+    GIRes R; gi_reset(R);
+    bool finished = false; f3 finalColor = splat3(0.0f);
+    Mat hm;
+    if (pp.hitDistance < 0.0f) { finished = true; finalColor = st.sky; }
+    else {
+        hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        if (length(emission(hm)) > 0.0f) { finished = true; finalColor = emission(hm); }
+    }
+    if (finished) {
+        fr.gi[i] = R; fr.depth[i] = pp.hitDistance;
+        if (inBand) epilogue(fr, i, rgb1(finalColor));
+        return;
+    }
+    {
+        const uint32_t originalSeed = seed;
+        f3 T = splat3(1.0f), Lo = splat3(0.0f), samplePoint = splat3(0.0f), sampleNormal = splat3(0.0f);
+        const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+        float pdf;
+        const f3 dir = sample_brdf(nrm3(pp), -pd, albedo, hm.metallic, hm.roughness, seed, pdf);
+        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+        const float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
+        T = T * ((brdf * cosT) / pdf);
+        f3 ro = pos3(pp) + nrm3(pp) * 1e-12f, rd = dir;
+        for (int b = 0; b < (int)st.maxBounces; ++b) {
+            seed += (uint32_t)(31 * b);
+            const Payload hit = trace_ray(sc, ro, rd, stk);
+            if (b == 0) { samplePoint = pos3(hit); sampleNormal = nrm3(hit); }
+            if (hit.hitDistance < 0.0f) { Lo = Lo + T * st.sky; break; }
+            const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
+            const f3 em = emission(m);
+            if (length(em) > 0.0f) { Lo = Lo + T * em; break; }
+            const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
+            float bpdf;
+            const f3 bdir = sample_brdf(nrm3(hit), -rd, alb, m.metallic, m.roughness, seed, bpdf);
+            const f3 bbrdf = eval_brdf(nrm3(hit), -rd, bdir, alb, m.metallic, m.roughness);
+            const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
+            T = T * ((bbrdf * bcos) / bpdf);
+            ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
+        }
+        GISample s; s.seed = originalSeed;
+        s.vp[0] = pp.px; s.vp[1] = pp.py; s.vp[2] = pp.pz;
+        const f2 vn = oct_encode(nrm3(pp)); s.vn[0] = vn.x; s.vn[1] = vn.y;
+        s.sp[0] = samplePoint.x; s.sp[1] = samplePoint.y; s.sp[2] = samplePoint.z;
+        const f2 sn = oct_encode(sampleNormal); s.sn[0] = sn.x; s.sn[1] = sn.y;
+        s.Lo[0] = Lo.x; s.Lo[1] = Lo.y; s.Lo[2] = Lo.z; s.pdf = 0.0f;
+        const float len = length(Lo);
+        gi_update(R, s, len, 1u, len, seed);
+        R.W = R.s.pdf > 0.0f ? ((1.0f / R.s.pdf) * R.wSum) / (float)R.M : 0.0f;
+    }
+    if (st.useTemporal) {
+        const uint32_t prevIdx = prev_pixel(cam, pos3(pp));
+        const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
+        GIRes prev = fr.giPrev[prevIdx];
+        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99;
+        const f3 plo = lo3(prev.s);
+        if (valid && prev.M > 0u && dot(plo, plo) > 0.0f) {
+            GIRes Tm = R;
+            const uint32_t lim = st.historyLimit * R.M;
+            prev.M = (lim < prev.M) ? lim : prev.M;
+            const float pdf = length(plo);
+            gi_update(Tm, prev.s, (pdf * prev.W) * (float)prev.M, prev.M, pdf, seed);
+            Tm.W = Tm.s.pdf > 0.0f ? Tm.s.pdf / ((float)Tm.M * Tm.s.pdf) : 0.0f;
+            gi_reset(R);
+            gi_merge(R, Tm, Tm.s.pdf, seed);
+        }
+    }
+    fr.gi[i] = R;
+    if (inBand) fr.image[i] = 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gi_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    uint32_t x, y;
+    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
+    int32_t* stk = s_stack + threadIdx.x;
+    const uint32_t i = x + y * fr.W;
+    if (fr.image[i] != 0u) return;
+    GIRes R = fr.gi[i];
+    const Payload pp = fr.payload[i];
+    uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
+    if (st.useSpatial) {
+        const float plen = length(lo3(R.s));
+        uint32_t Z = plen > 0.0f ? R.M : 0u;
+        for (uint32_t n = 0; n < st.numNeighbors; ++n) {
+            const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+            const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
+            const GIRes N = fr.gi[ni];
+            const float nlen = length(lo3(N.s));
+            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906 || nlen == 0.0f) continue;
+            Z += N.M;
+            f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
+            const f3 sn = oct_decode(sne);
+            const f3 nvp = mk3(N.s.vp[0], N.s.vp[1], N.s.vp[2]), nsp = mk3(N.s.sp[0], N.s.sp[1], N.s.sp[2]);
+            const f3 rvp = mk3(R.s.vp[0], R.s.vp[1], R.s.vp[2]);
+            const f3 dQ = normalize(nvp - nsp);
+            const float cosQ = dot(sn, dQ);
+            const f3 dR = normalize(rvp - nsp);
+            const float cosR = dot(sn, dR);
+            const float jl = cosQ > 0.0f ? cosR / cosQ : 0.0f;
+            const float distQ = length(nvp - nsp), distR = length(rvp - nsp);
+            const float jr = distR > 0.0f ? (distQ * distQ) / (distR * distR) : 0.0f;
+            const float jac = jl * jr;
+            float pdf = jac > 0.0f ? nlen / jac : 0.0f;
+            const Payload hit = trace_ray(sc, nsp, dR, stk);
+            const float tol = gmax(1e-4f, distR * 1e-3f);
+            if (!(__builtin_fabsf(hit.hitDistance - distR) <= tol)) pdf = 0.0f;
+            gi_merge(R, N, pdf, seed);
+        }
+        R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;
+    }
+    const f3 radiance = lo3(R.s) * R.W;
+    fr.depth[i] = pp.hitDistance;
+    fr.giPrev[i] = R;
+    epilogue(fr, i, rgb1(radiance));
+}
+
+}  // namespace rt

@@ -1,0 +1,231 @@
+/*
+ * fyprt.h — C ABI of the MI355X-native trace + shade path (libfyprt.so).
+ *
+ * This is the drop-in boundary for ONE path of Savasstion/FYPRayTracer: everything
+ * `Renderer::Render` does between "scene/camera are on the host" and "RGBA8 + float4
+ * accumulation are back on the host" (reference: FYPRayTracer/src/Classes/Core/Renderer.cu:13-284
+ * and the 11 __global__ kernels it launches, Renderer.cu:2431-2900).  Plain pointers and sizes
+ * only; no C++, HIP or torch types cross this boundary.  Each entry point cites the
+ * reference interface it replaces.  The reference-side binding a maintainer would add is
+ * shown in INTEGRATION.md.
+ *
+ * Error convention: every call returns FYPRT_OK (0) or a negative FYPRT_E* code and
+ * records a message retrievable with fyprt_last_error().  (The reference prints
+ * cudaGetErrorString to stderr and keeps going, Renderer.cu:29-47; the C++ facade in
+ * fypraytracer_amd/host/ reproduces that on top of these codes.)
+ *
+ * Threading: one context per host thread and per GPU; a context owns one HIP stream.
+ */
+#ifndef FYPRT_H
+#define FYPRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FYPRT_OK 0
+#define FYPRT_EINVAL (-1)   /* bad argument / inconsistent scene description            */
+#define FYPRT_EHIP (-2)     /* a HIP runtime call failed (message has hipGetErrorString) */
+#define FYPRT_ESTATE (-3)   /* call order violated (render before resize/scene/camera)   */
+#define FYPRT_ENOLIGHT (-4) /* light-based technique on a scene with no emissive triangle
+                               (the reference reads out of bounds there)                 */
+
+/* SamplingTechniqueEnum.h:4-17 — values fixed by the reference's enum order. */
+enum fyprt_technique {
+    FYPRT_BRUTE_FORCE = 0,
+    FYPRT_UNIFORM_SAMPLING = 1,
+    FYPRT_COSINE_WEIGHTED_SAMPLING = 2,
+    FYPRT_GGX_SAMPLING = 3,
+    FYPRT_BRDF_SAMPLING = 4,
+    FYPRT_LIGHT_SOURCE_SAMPLING = 5,
+    FYPRT_NEE = 6,
+    FYPRT_RESTIR_DI = 7,
+    FYPRT_RESTIR_GI = 8
+};
+
+/* RenderingSettings.h:5-22 — field-for-field, 52 bytes, so the reference's struct can be
+ * passed by address (bool == 1 byte + padding under both the MSVC x64 and SysV ABIs). */
+typedef struct fyprt_settings {
+    uint8_t to_accumulate;          /* toAccumulate */
+    uint8_t _pad0[3];
+    int32_t light_bounces;          /* lightBounces   (cast to uint8_t by the kernels, Renderer.cu:2444) */
+    int32_t sample_count;           /* sampleCount    (cast to uint8_t, Renderer.cu:2480-2481)            */
+    float sky_color[3];             /* skyColor */
+    int32_t technique;              /* currentSamplingTechnique (enum fyprt_technique) */
+    int32_t light_candidate_count;  /* lightCandidateCount */
+    uint32_t rand_seed;             /* randSeed */
+    uint8_t use_temporal_reuse;     /* useTemporalReuse */
+    uint8_t use_spatial_reuse;      /* useSpatialReuse */
+    uint8_t _pad1[2];
+    int32_t temporal_history_limit; /* temporalHistoryLimit   (cast to uint8_t, Renderer.cu:1775) */
+    int32_t spatial_neighbor_num;   /* spatialNeighborNum     (cast to uint8_t, Renderer.cu:1896) */
+    int32_t spatial_neighbor_radius;/* spatialNeighborRadius  (cast to uint8_t, Renderer.cu:1897) */
+} fyprt_settings;
+
+/* Vertex.h:5-10 (32 B): world-space vertices, i.e. Scene::worldVertices (Scene.cpp:42-51). */
+typedef struct fyprt_vertex { float position[3]; float normal[3]; float uv[2]; } fyprt_vertex;
+
+/* Material.cuh:7-16 (44 B).  is_use_albedo_map overlays the reference's `bool` + 3 padding
+ * bytes: only the low byte is read. */
+typedef struct fyprt_material {
+    uint32_t is_use_albedo_map;
+    float albedo[3];
+    uint32_t albedo_map_index;
+    float roughness, metallic;
+    float emission_color[3];
+    float emission_power;
+} fyprt_material;
+
+/* Mesh.h:26-31 reduced to what the path reads: the triangle range of the mesh inside
+ * Scene::triangles (indexStart/3, indexCount/3) and its material. */
+typedef struct fyprt_mesh { uint32_t first_triangle, triangle_count; int32_t material_index; } fyprt_mesh;
+
+/* Texture.cuh:9-14: ABGR8 pixels (A<<24|B<<16|G<<8|R), row-major. */
+typedef struct fyprt_texture { const uint32_t* pixels; uint32_t width, height; } fyprt_texture;
+
+/* LightTree.cuh:28-49 flattened (plain floats, explicit centroid because the reference's
+ * UnionAABB leaves inner-node centroids at the origin, AABB.cuh:43-57). 80 bytes. */
+typedef struct fyprt_lighttree_node {
+    float energy;
+    uint32_t num_emitters;
+    uint32_t left;            /* Node::offset       (left child, inner nodes)                   */
+    uint32_t right_or_emitter;/* Node::emitterIndex (right child | triangle index | mesh index) */
+    uint32_t is_leaf;
+    float cone_axis[3], theta_o, theta_e;   /* bounds_o */
+    float box_lo[3], box_hi[3], box_centroid[3]; /* bounds_w */
+    uint32_t _pad;
+} fyprt_lighttree_node;
+
+/* Optional prebuilt light trees in the reference's own shape (Scene::lightTree_tlas +
+ * Mesh::lightTree_blas).  If `tlas_nodes` is NULL the library builds them itself with its
+ * restatement of LightTree.cpp:21-293 (needed only by LIGHT_SOURCE_SAMPLING and NEE). */
+typedef struct fyprt_lighttrees {
+    const fyprt_lighttree_node* tlas_nodes; uint32_t tlas_node_count, tlas_root;
+    const fyprt_lighttree_node* blas_nodes;  /* all per-mesh trees concatenated              */
+    const uint32_t* blas_first;              /* [mesh_count] first node of mesh m's tree     */
+    const uint32_t* blas_count;              /* [mesh_count] node count (0 = mesh not a light)*/
+    const uint32_t* blas_root;               /* [mesh_count] root index relative to blas_first*/
+} fyprt_lighttrees;
+
+/* What SceneToGPU deep-copies (Scene_GPU.cpp:6-81), as flat arrays + counts. */
+typedef struct fyprt_scene_desc {
+    const fyprt_vertex* vertices; uint32_t vertex_count;          /* Scene::worldVertices */
+    const void* triangles; uint32_t triangle_count; uint32_t triangle_stride;
+        /* Scene::triangles: each record starts with {uint32 v0,v1,v2; int32 materialIndex}
+           (Triangle.cuh:9-10); stride 52 passes the reference's array as is, 16 a packed one. */
+    const fyprt_material* materials; uint32_t material_count;     /* Scene::materials */
+    const fyprt_mesh* meshes; uint32_t mesh_count;                /* Scene::meshes    */
+    const fyprt_texture* textures; uint32_t texture_count;        /* Scene::textures  */
+    const uint32_t* emissive_triangles; uint32_t emissive_count;  /* Scene::emissiveTriangles; NULL = derive
+                                                                     as InitSceneEmissiveTriangles, Scene.cpp:209-221 */
+    const fyprt_lighttrees* light_trees;                          /* may be NULL */
+} fyprt_scene_desc;
+
+/* What CameraToGPU uploads (Camera_GPU.cu:4-60) minus the W*H ray-direction array, which is
+ * regenerated on the device from inverse_projection / inverse_view with the arithmetic of
+ * Camera::RecalculateRayDirections (Camera.cpp:136-153).  Matrices are column-major float[16]
+ * exactly as glm::mat4 stores them. */
+typedef struct fyprt_camera_desc {
+    float projection[16], view[16], prev_projection[16], prev_view[16];
+    float inverse_projection[16], inverse_view[16];
+    float position[3];
+    uint32_t viewport_width, viewport_height;
+} fyprt_camera_desc;
+
+typedef struct fyprt_context fyprt_context;
+
+/* Per-frame statistics of the last fyprt_render call. */
+typedef struct fyprt_frame_stats {
+    float kernel_ms;        /* hipEvent time over the frame's kernels on the context stream */
+    float kernel_ms_part[4];/* per launch (trace/shade, DI/GI part 1, part 2, ...), 0 if unused */
+    uint64_t rays;          /* TraceRay invocations (only when built/run with counting on)  */
+    uint32_t launches;
+} fyprt_frame_stats;
+
+/* Buffers readable with fyprt_read_buffer (device -> host, for parity tests). */
+enum fyprt_buffer {
+    FYPRT_BUF_ACCUM = 0,        /* float4 running sum          (Renderer.h:21 m_AccumulationData) */
+    FYPRT_BUF_IMAGE = 1,        /* uint32 ABGR8                (Renderer.h:20 m_RenderImageData)  */
+    FYPRT_BUF_PAYLOAD = 2,      /* RayHitPayload 40 B          (Renderer.h:31)                    */
+    FYPRT_BUF_DEPTH = 3,        /* float                       (Renderer.h:29)                    */
+    FYPRT_BUF_NORMAL = 4,       /* float2 octahedral, the frame just rendered (Renderer.h:30)     */
+    FYPRT_BUF_DI_RESERVOIR = 5, /* ReSTIR_DI_Reservoir 20 B, after Part 1 (Renderer.h:34)         */
+    FYPRT_BUF_DI_PREV = 6,      /* ... written by Part 2       (Renderer.h:35)                    */
+    FYPRT_BUF_GI_RESERVOIR = 7, /* ReSTIR_GI_Reservoir 72 B    (Renderer.h:38)                    */
+    FYPRT_BUF_GI_PREV = 8       /*                             (Renderer.h:39)                    */
+};
+
+/* ---- lifetime (the reference has none: Renderer owns raw pointers and never frees them,
+ *      Renderer.cu:421-457 FreeDynamicallyAllocatedMemory is never called) */
+int fyprt_create(int device_ordinal, fyprt_context** out);
+void fyprt_destroy(fyprt_context* ctx);
+const char* fyprt_last_error(const fyprt_context* ctx);   /* ctx may be NULL: last create error */
+
+/* Renderer::OnResize + ResizeReservoirs/DepthBuffers/NormalBuffers/PrimaryHitPayloadBuffers
+ * (Renderer.cpp:5-41, Renderer.cu:286-419): (re)allocates and zero-fills every per-pixel
+ * buffer and resets the frame index to 1.  Unlike the reference the device buffers exist
+ * after the FIRST call (Renderer.cpp:24-27 skips them). */
+int fyprt_resize(fyprt_context* ctx, uint32_t width, uint32_t height);
+
+/* Multi-GPU tile split (new; BASELINE.json north_star): this context renders image rows
+ * [row_begin,row_end) of the full width x height frame.  ReSTIR Part 1 is additionally run
+ * on `halo_rows` rows either side (halo recompute).  Default: all rows. */
+int fyprt_set_rows(fyprt_context* ctx, uint32_t row_begin, uint32_t row_end, uint32_t halo_rows);
+
+/* SceneToGPU / FreeSceneGPU (Scene_GPU.cpp:6-163) + Renderer::SetSceneToBeUpdatedFlag(true)
+ * (Renderer.h:56): builds the acceleration structure and uploads everything. */
+int fyprt_upload_scene(fyprt_context* ctx, const fyprt_scene_desc* scene);
+
+/* CameraToGPU (Camera_GPU.cu:4-60), called by Renderer::Render every frame (Renderer.cu:70). */
+int fyprt_set_camera(fyprt_context* ctx, const fyprt_camera_desc* camera);
+
+/* Renderer::Render (Renderer.cu:13-284): one frame with the given settings: selects the
+ * technique's kernel(s) (Renderer.cu:87-235), accumulates, tonemaps and packs on the device,
+ * then advances the frame index (Renderer.cu:258-261).  Blocking. `stats` may be NULL. */
+int fyprt_render(fyprt_context* ctx, const fyprt_settings* settings, fyprt_frame_stats* stats);
+
+/* Asynchronous variant: enqueues the frame on the context's stream and returns. */
+int fyprt_render_async(fyprt_context* ctx, const fyprt_settings* settings);
+int fyprt_synchronize(fyprt_context* ctx);
+
+/* The D2H copies at Renderer.cu:244-250: rgba8 = m_RenderImageData (ABGR8, row 0 = NDC y -1),
+ * accum4 = m_AccumulationData (float4 running SUM).  Either may be NULL.  Full frame size;
+ * rows outside this context's band are left untouched. */
+int fyprt_readback(fyprt_context* ctx, uint32_t* rgba8, float* accum4);
+
+/* Device pointer of the ABGR8 image (width*height uint32) for an on-device gather (RCCL). */
+int fyprt_image_device_ptr(fyprt_context* ctx, void** dptr);
+/* Render into a caller-owned device image buffer (e.g. a torch tensor) instead of the internal one. */
+int fyprt_set_external_image(fyprt_context* ctx, void* device_ptr);
+/* The context's hipStream_t (as void*) so a caller can order its own work after a frame. */
+int fyprt_stream(fyprt_context* ctx, void** stream);
+
+int fyprt_read_buffer(fyprt_context* ctx, int which /* enum fyprt_buffer */, void* dst, size_t bytes);
+
+/* Renderer::ResetFrameIndex / GetCurrentFrameIndex (Renderer.h:47,49). */
+int fyprt_reset_frame_index(fyprt_context* ctx);
+uint32_t fyprt_frame_index(const fyprt_context* ctx);
+
+/* Export of the library's own acceleration structure as plain arrays, so an
+ * instrumented CPU restatement of the same traversal can count box / triangle tests
+ * (SURVEY.md §8d).  Call with NULL pointers to query the counts. */
+int fyprt_export_bvh(fyprt_context* ctx, void* nodes64, uint32_t* node_count, void* tris48,
+                     uint32_t* tri_count, int32_t* root_ref, uint32_t* max_depth);
+/* Export of the light trees the library built (same flat node format as the input). */
+int fyprt_export_lighttrees(fyprt_context* ctx, fyprt_lighttree_node* tlas, uint32_t* tlas_count, uint32_t* tlas_root,
+                            fyprt_lighttree_node* blas, uint32_t* blas_total, uint32_t* blas_first,
+                            uint32_t* blas_count, uint32_t* blas_root);
+
+/* Count TraceRay invocations on the device (atomic per wave); off by default. */
+int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
+
+/* Library / build identification ("fyprt <version> gfx950 ..."). */
+const char* fyprt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FYPRT_H */

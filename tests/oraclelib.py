@@ -1,0 +1,164 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE (the checker), never the product.
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from fypraytracer_amd import capi
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
+
+
+def _load(name):
+    p = ORACLE_DIR / name
+    if not p.exists():
+        build()
+    lib = C.CDLL(str(p))
+    vp, u32 = C.c_void_p, C.c_uint32
+    lib.orc_create.argtypes = [C.POINTER(capi.SceneDesc)]
+    lib.orc_create.restype = vp
+    lib.orc_destroy.argtypes = [vp]
+    lib.orc_emissive_count.argtypes = [vp]
+    lib.orc_emissive_count.restype = u32
+    lib.orc_get_emissive.argtypes = [vp, vp]
+    lib.orc_resize.argtypes = [vp, u32, u32]
+    lib.orc_use_reference_tracer.argtypes = [vp]
+    lib.orc_set_product_bvh.argtypes = [vp, vp, u32, vp, u32, C.c_int32]
+    lib.orc_set_camera.argtypes = [vp, C.POINTER(capi.CameraDesc)]
+    lib.orc_reset_frame_index.argtypes = [vp]
+    lib.orc_frame_index.argtypes = [vp]
+    lib.orc_frame_index.restype = u32
+    lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_max_threads.restype = C.c_int
+    lib.orc_render.argtypes = [vp, C.POINTER(capi.Settings), u32, u32, u32, vp]
+    lib.orc_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.orc_read_buffer.restype = C.c_size_t
+    lib.orc_lighttree_tlas_count.argtypes = [vp]
+    lib.orc_lighttree_tlas_count.restype = u32
+    lib.orc_lighttree_blas_total.argtypes = [vp]
+    lib.orc_lighttree_blas_total.restype = u32
+    lib.orc_export_lighttrees.argtypes = [vp, vp, C.POINTER(u32), vp, vp, vp, vp]
+    lib.orc_reference_bvh_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(u32)]
+    lib.orc_trace.argtypes = [vp, vp, vp, vp, vp]
+    lib.orc_ray_direction.argtypes = [vp, u32, u32, vp]
+    lib.orc_pcg_hash.argtypes = [u32]
+    lib.orc_pcg_hash.restype = u32
+    lib.orc_random_float.argtypes = [C.POINTER(u32)]
+    lib.orc_random_float.restype = C.c_float
+    for f in ("orc_sin", "orc_cos", "orc_acos", "orc_pow5"):
+        getattr(lib, f).argtypes = [C.c_float]
+        getattr(lib, f).restype = C.c_float
+    lib.orc_uniform_pdf.restype = C.c_float
+    lib.orc_encode_oct.argtypes = [vp, vp]
+    lib.orc_decode_oct.argtypes = [vp, vp]
+    lib.orc_convert_rgba.argtypes = [vp]
+    lib.orc_convert_rgba.restype = u32
+    lib.orc_brdf.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, vp]
+    lib.orc_sample.argtypes = [C.c_int, vp, vp, vp, C.c_float, C.c_float, C.POINTER(u32), vp]
+    lib.orc_di_reset_update.argtypes = [u32, C.c_float, C.c_float, C.POINTER(u32), vp, C.POINTER(C.c_int)]
+    lib.orc_sample_bilinear.argtypes = [vp, u32, u32, C.c_float, C.c_float]
+    lib.orc_sample_bilinear.restype = u32
+    return lib
+
+
+_libs = {}
+
+
+def lib(libm=False):
+    name = "liboracle_libm.so" if libm else "liboracle.so"
+    if name not in _libs:
+        _libs[name] = _load(name)
+    return _libs[name]
+
+
+class Oracle:
+    """CPU restatement of Renderer::Render for one scene (reference traversal by default)."""
+
+    def __init__(self, scene, width, height, libm=False):
+        self.lib = lib(libm)
+        d, keep = capi.make_scene_desc(scene)
+        self.h = C.c_void_p(self.lib.orc_create(C.byref(d)))
+        self.width, self.height = width, height
+        self.lib.orc_resize(self.h, width, height)
+        self.mesh_count = len(scene.meshes)
+
+    def close(self):
+        if self.h:
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, cam):
+        c = capi.make_camera_desc(cam)
+        self.lib.orc_set_camera(self.h, C.byref(c))
+
+    def use_product_bvh(self, bvh):
+        n, t = np.ascontiguousarray(bvh["nodes"]), np.ascontiguousarray(bvh["tris"])
+        self.lib.orc_set_product_bvh(self.h, n.ctypes.data, len(n), t.ctypes.data, len(t), int(bvh["root"]))
+
+    def use_reference_tracer(self):
+        self.lib.orc_use_reference_tracer(self.h)
+
+    def reset_frame_index(self):
+        self.lib.orc_reset_frame_index(self.h)
+
+    def render(self, settings, rows=None, halo=0):
+        y0, y1 = rows if rows else (0, self.height)
+        cnt = (C.c_uint64 * 4)()
+        self.lib.orc_render(self.h, C.byref(settings), y0, y1, halo, cnt)
+        return {"rays": cnt[0], "box_tests": cnt[1], "tri_tests": cnt[2], "hits": cnt[3]}
+
+    def read_buffer(self, which):
+        dt = capi.BUFFER_DTYPES[which]
+        out = np.empty(self.width * self.height, dtype=dt)
+        n = self.lib.orc_read_buffer(self.h, which, out.ctypes.data, out.nbytes)
+        assert n == out.nbytes, (n, out.nbytes)
+        return out
+
+    def image(self):
+        return self.read_buffer(capi.BUF_IMAGE).reshape(self.height, self.width)
+
+    def accum(self):
+        return self.read_buffer(capi.BUF_ACCUM).reshape(self.height, self.width, 4)
+
+    def emissive(self):
+        n = self.lib.orc_emissive_count(self.h)
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            self.lib.orc_get_emissive(self.h, out.ctypes.data)
+        return out
+
+    def export_lighttrees(self):
+        tc, bt = self.lib.orc_lighttree_tlas_count(self.h), self.lib.orc_lighttree_blas_total(self.h)
+        tlas = np.zeros(tc, dtype=capi.LT_NODE_DTYPE)
+        blas = np.zeros(bt, dtype=capi.LT_NODE_DTYPE)
+        first = np.zeros(self.mesh_count, dtype=np.uint32)
+        count = np.zeros(self.mesh_count, dtype=np.uint32)
+        root = np.zeros(self.mesh_count, dtype=np.uint32)
+        tr = C.c_uint32()
+        self.lib.orc_export_lighttrees(self.h, tlas.ctypes.data, C.byref(tr), blas.ctypes.data, first.ctypes.data,
+                                       count.ctypes.data, root.ctypes.data)
+        return {"tlas": tlas, "tlas_root": tr.value, "blas": blas, "blas_first": first, "blas_count": count,
+                "blas_root": root}
+
+    def trace(self, origin, direction):
+        o = np.asarray(origin, dtype=np.float32)
+        d = np.asarray(direction, dtype=np.float32)
+        p = np.zeros(1, dtype=capi.PAYLOAD_DTYPE)
+        cnt = (C.c_uint64 * 4)()
+        self.lib.orc_trace(self.h, o.ctypes.data, d.ctypes.data, p.ctypes.data, cnt)
+        return p[0], {"box_tests": cnt[1], "tri_tests": cnt[2]}
