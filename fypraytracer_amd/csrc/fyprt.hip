@@ -89,8 +89,8 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
-    (void)c->rayCounter.alloc(1);
-    (void)hipMemset(c->rayCounter.p, 0, 8);
+    (void)c->rayCounter.alloc(16);
+    (void)hipMemset(c->rayCounter.p, 0, 128);
     *out = c;
     return FYPRT_OK;
 }
@@ -294,7 +294,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
-    if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 8, c->stream));
+    if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
@@ -319,6 +319,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             else hipLaunchKernelGGL(k_gi_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+            if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
             else hipLaunchKernelGGL(k_gi_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
             launches = 2;
@@ -344,7 +345,13 @@ int fyprt_render(fyprt_context* c, const fyprt_settings* s, fyprt_frame_stats* s
         float total = 0.0f;
         for (int k = 0; k < c->lastLaunches; ++k) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]); stats->kernel_ms_part[k] = ms; total += ms; }
         stats->kernel_ms = total;
-        if (c->countRays) { unsigned long long r = 0; (void)hipMemcpy(&r, c->rayCounter.p, 8, hipMemcpyDeviceToHost); stats->rays = r; }
+        if (c->countRays) {
+            unsigned long long r[16] = {0}; (void)hipMemcpy(r, c->rayCounter.p, 128, hipMemcpyDeviceToHost);
+            for (int k = 0; k < 4; ++k) {
+                stats->part_rays[k] = r[4 * k + 0]; stats->part_box_tests[k] = r[4 * k + 1]; stats->part_tri_tests[k] = r[4 * k + 2]; stats->part_hits[k] = r[4 * k + 3];
+                stats->rays += r[4 * k + 0]; stats->box_tests += r[4 * k + 1]; stats->tri_tests += r[4 * k + 2]; stats->hits += r[4 * k + 3];
+            }
+        }
     }
     return FYPRT_OK;
 }

@@ -26,7 +26,7 @@ struct DevScene {
     const uint32_t* emissive; uint32_t emissiveCount;
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
     const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot;
-    unsigned long long* rayCounter;   // nullptr = counting off
+    unsigned long long* rayCounter;   // nullptr = counting off; else [0] rays [1] box tests [2] triangle tests [3] hits
 };
 
 struct DevCamera { m4 invProj, invView, prevProjView; f3 position; uint32_t W, H; };
@@ -77,11 +77,9 @@ RT_DEV float safe_inv(float d) { return 1.0f / ((__builtin_fabsf(d) < 1e-30f) ? 
 // accepting t > 1e-4 && t < closest, no back-face culling.
 RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     Hit h; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.tri = -1;
-    if (sc.rayCounter) {
-        unsigned long long m = __ballot(1);
-        if ((__lane_id() == (unsigned)__builtin_ctzll(m))) atomicAdd(sc.rayCounter, (unsigned long long)__popcll(m));
-    }
-    if (sc.triCount == 0) return h;
+    const bool counting = sc.rayCounter != nullptr;        // wave-uniform (kernel argument)
+    uint32_t nBox = 0, nTri = 0;
+    if (sc.triCount == 0) { if (counting) atomicAdd(sc.rayCounter, 1ull); return h; }
     const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
     float closestInfl = h.t * 1.000001f;
     Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
@@ -90,6 +88,7 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
         while (cur >= 0) {
             const float4* n = sc.nodes + (size_t)cur * 4;
             const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            if (counting) nBox += 2;
             // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
             float ax = (q0.x - o.x) * ix, bx = (q0.w - o.x) * ix;
             float ay = (q0.y - o.y) * iy, by = (q1.x - o.y) * iy;
@@ -116,6 +115,7 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
         for (uint32_t k = 0; k < cnt; ++k) {
             const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
             const float4 a = tp[0], b = tp[1], c = tp[2];
+            if (counting) nTri += 1;
             const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
             const f3 hh = cross(d, e2);
             const float det = dot(e1, hh), f = 1.0f / det;
@@ -129,6 +129,10 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
             if (t > 0.0001f && t < h.t) { h.t = t; h.u = u; h.v = v; h.tri = __float_as_int(c.y); closestInfl = t * 1.000001f; }
         }
         cur = st.pop();
+    }
+    if (counting) {     // SURVEY.md §8(d) instrumentation; same counts as the oracle's restatement (tests/test_gpu_counters.py)
+        atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
+        atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, (unsigned long long)(h.tri >= 0 ? 1 : 0));
     }
     return h;
 }

@@ -141,7 +141,11 @@ typedef struct fyprt_context fyprt_context;
 typedef struct fyprt_frame_stats {
     float kernel_ms;        /* hipEvent time over the frame's kernels on the context stream */
     float kernel_ms_part[4];/* per launch (trace/shade, DI/GI part 1, part 2, ...), 0 if unused */
-    uint64_t rays;          /* TraceRay invocations (only when built/run with counting on)  */
+    uint64_t rays;          /* TraceRay invocations            } only with fyprt_set_ray_counting(ctx, 1):    */
+    uint64_t box_tests;     /* AABB slab tests executed        } the SURVEY.md §8(d) instrumentation, exact    */
+    uint64_t tri_tests;     /* ray/triangle tests executed     } per-lane counts reduced with device atomics   */
+    uint64_t hits;          /* rays that found a triangle      }                                               */
+    uint64_t part_rays[4], part_box_tests[4], part_tri_tests[4], part_hits[4];   /* the same, per launch */
     uint32_t launches;
 } fyprt_frame_stats;
 
@@ -219,7 +223,7 @@ int fyprt_export_lighttrees(fyprt_context* ctx, fyprt_lighttree_node* tlas, uint
                             fyprt_lighttree_node* blas, uint32_t* blas_total, uint32_t* blas_first,
                             uint32_t* blas_count, uint32_t* blas_root);
 
-/* Count TraceRay invocations on the device (atomic per wave); off by default. */
+/* Count rays / box tests / triangle tests on the device (atomics; slows the frame); off by default. */
 int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
 
 /* Library / build identification ("fyprt <version> gfx950 ..."). */
