@@ -62,7 +62,7 @@ def main():
         raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
 
     import torch
-    from fypraytracer_amd import capi, scenes
+    from fypraytracer_amd import capi, multigpu, scenes
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -85,9 +85,9 @@ def main():
                        light_candidate_count=4, use_temporal_reuse=1, use_spatial_reuse=1, temporal_history_limit=2,
                        spatial_neighbor_num=5, spatial_neighbor_radius=30)
     restir = tech in (7, 8)
-    halo = st.spatial_neighbor_radius if (restir and N > 1) else 0
+    halo = multigpu.halo_rows(st, tech, N)
     rows_per = (H + N - 1) // N
-    r0, r1 = min(H, rank * rows_per), min(H, (rank + 1) * rows_per)
+    r0, r1 = multigpu.band_rows(H, N, rank)
 
     ctx = capi.Context(local_rank)
     ctx.resize(W, H)
@@ -100,10 +100,11 @@ def main():
     # the image lives in a torch tensor so the RCCL gather needs no copy
     image = torch.zeros(H * W, dtype=torch.int32, device="cuda")
     ctx.set_external_image(image.data_ptr())
-    gathered = torch.empty(N * rows_per * W, dtype=torch.int32, device="cuda") if N > 1 else None
+    gathered = None
     ext_stream = torch.cuda.ExternalStream(ctx.stream()) if N > 1 else None
 
     frame_no = [0]
+    gathered_box = [gathered]
     part_ms = np.zeros(4)
 
     def step(collect=False):
@@ -114,8 +115,8 @@ def main():
             part_ms[:] += np.array(list(s.kernel_ms_part))
         if N > 1:
             band = image[r0 * W: r0 * W + rows_per * W] if r1 - r0 == rows_per else torch.nn.functional.pad(image[r0 * W: r1 * W], (0, (rows_per - (r1 - r0)) * W))
-            with torch.cuda.stream(ext_stream):
-                dist.all_gather_into_tensor(gathered, band)
+            with torch.cuda.stream(ext_stream):           # ordered after the frame's kernels on the context stream
+                gathered_box[0] = multigpu.gather_image(band, H, W, N, dist)
         return s
 
     def fence():

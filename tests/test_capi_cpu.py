@@ -1,0 +1,133 @@
+"""CPU-side tests of the C-ABI library: it loads, exports every symbol include/fyprt.h declares, keeps
+the documented struct layouts, validates its inputs, and its host builders (acceleration structure,
+light trees) satisfy their invariants.  No compute call is made without a GPU."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from common import struct_equal
+from fypraytracer_amd import capi, scenes
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "fyprt.h").read_text()
+    declared = sorted(set(re.findall(r"\b(fyprt_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 20
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"libfyprt.so does not export {name}"
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+    assert b"gfx950" in lib.fyprt_version()
+
+
+def test_struct_layouts_match_reference_sizes():
+    # RenderingSettings 52 B, Vertex 32 B, Material 44 B, RayHitPayload 40 B, DI reservoir 20 B, GI reservoir 72 B
+    assert C.sizeof(capi.Settings) == 52 and capi.VERTEX_DTYPE.itemsize == 32 and capi.MATERIAL_DTYPE.itemsize == 44
+    assert capi.PAYLOAD_DTYPE.itemsize == 40 and capi.DI_DTYPE.itemsize == 20 and capi.GI_DTYPE.itemsize == 72
+    s = capi.Settings()
+    assert (s.to_accumulate, s.light_bounces, s.sample_count, s.technique, s.light_candidate_count, s.rand_seed) == (1, 1, 1, 0, 4, 1)
+    assert (s.use_temporal_reuse, s.use_spatial_reuse, s.temporal_history_limit, s.spatial_neighbor_num, s.spatial_neighbor_radius) == (0, 0, 2, 5, 30)
+    assert tuple(s.sky_color) == (1.0, 1.0, 1.0)                     # RenderingSettings.h:7-21 defaults
+    assert capi.Settings.technique.offset == 24 and capi.Settings.rand_seed.offset == 32 and capi.Settings.temporal_history_limit.offset == 40
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.FyprtError):
+        capi.Context(0)
+    missing = ROOT / "fypraytracer_amd" / "csrc" / "does_not_exist.so"
+    with pytest.raises(capi.FyprtError):
+        capi.load_library(missing)
+
+
+def test_host_only_context_refuses_to_render_and_validates_scenes():
+    ctx = capi.Context(-1)
+    with pytest.raises(capi.FyprtError):
+        ctx.resize(16, 16)
+    sc = scenes.cornell_box()
+    ctx.upload_scene(sc)
+    with pytest.raises(capi.FyprtError):
+        ctx.render(capi.Settings())
+    bad = scenes.cornell_box()
+    bad.triangles = bad.triangles.copy()
+    bad.triangles["v0"][3] = 10_000                                   # vertex index out of range
+    with pytest.raises(capi.FyprtError, match="out of range"):
+        ctx.upload_scene(bad)
+    bad2 = scenes.cornell_box()
+    bad2.meshes = bad2.meshes[:-1]                                    # meshes no longer partition the triangles
+    with pytest.raises(capi.FyprtError, match="partition"):
+        ctx.upload_scene(bad2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["cornell", "hall_small"])
+def test_bvh_invariants(name):
+    sc = scenes.cornell_box() if name == "cornell" else scenes.hall_scene_small()
+    ctx = capi.Context(-1)
+    ctx.upload_scene(sc)
+    b = ctx.export_bvh()
+    nodes, tris = b["nodes"], b["tris"]
+    assert sorted(tris["tri"].tolist()) == list(range(len(sc.triangles)))   # every triangle exactly once
+    assert b["max_depth"] + 2 <= 80                                          # fits the traversal stack (24 LDS + 56 spill)
+    pos = sc.world_vertices["position"]
+    t = sc.triangles
+    # leaf records are (v0, v1 - v0, v2 - v0) of the original triangle, bit for bit
+    i = tris["tri"]
+    assert np.array_equal(tris["v0"], pos[t["v0"][i]])
+    assert np.array_equal(tris["e1"], pos[t["v1"][i]] - pos[t["v0"][i]])
+    assert np.array_equal(tris["e2"], pos[t["v2"][i]] - pos[t["v0"][i]])
+    # every child box bounds everything below it; every node reachable exactly once from the root
+    tri_lo = np.minimum(np.minimum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
+    tri_hi = np.maximum(np.maximum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
+    seen = np.zeros(len(nodes), dtype=int)
+
+    def bounds(ref):
+        if ref >= 0:
+            seen[ref] += 1
+            n = nodes[ref]
+            l0, h0 = bounds(int(n["child0"]))
+            l1, h1 = bounds(int(n["child1"]))
+            assert (n["lo0"] <= l0).all() and (n["hi0"] >= h0).all() and (n["lo1"] <= l1).all() and (n["hi1"] >= h1).all()
+            return np.minimum(n["lo0"], n["lo1"]), np.maximum(n["hi0"], n["hi1"])
+        code = ~ref
+        first, cnt = code >> 2, (code & 3) + 1
+        ids = tris["tri"][first:first + cnt]
+        return tri_lo[ids].min(0), tri_hi[ids].max(0)
+
+    import sys
+    sys.setrecursionlimit(10000)
+    bounds(b["root"])
+    assert (seen == 1).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["cornell", "hall_small"])
+def test_light_trees_equal_the_oracles_restatement(oracle_built, name):
+    """LIGHT_SOURCE_SAMPLING / NEE parity hinges on the light trees (LightTree.cpp:21-293, quirks included):
+    the library's builder and the oracle's independent restatement must agree bit for bit."""
+    from oraclelib import Oracle
+    sc = scenes.cornell_box() if name == "cornell" else scenes.hall_scene_small()
+    ctx = capi.Context(-1)
+    ctx.upload_scene(sc)
+    mine = ctx.export_lighttrees(len(sc.meshes))
+    orc = Oracle(sc, 8, 8)
+    ref = orc.export_lighttrees()
+    assert mine["tlas_root"] == ref["tlas_root"] and len(mine["tlas"]) == len(ref["tlas"]) > 0
+    for k in ("tlas", "blas"):
+        assert struct_equal(mine[k], ref[k]).all()
+    for k in ("blas_first", "blas_count", "blas_root"):
+        assert np.array_equal(mine[k], ref[k])
+    # prebuilt trees (option (i) of the boundary) are accepted and exported unchanged
+    ctx2 = capi.Context(-1)
+    ctx2.upload_scene(sc, light_trees=ref)
+    again = ctx2.export_lighttrees(len(sc.meshes))
+    assert struct_equal(again["tlas"], ref["tlas"]).all() and struct_equal(again["blas"], ref["blas"]).all()
+    assert np.array_equal(orc.emissive(), sc.emissive_triangles)
+    ctx.close(); ctx2.close()
