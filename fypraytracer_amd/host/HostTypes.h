@@ -1,0 +1,102 @@
+// glm-free stand-ins with the reference's member names (Vertex.h, Triangle.cuh, Material.cuh, Mesh.h,
+// Texture.cuh, Scene.h, Camera.h) — just enough of the scene API to drive the facade headlessly.
+// Byte layouts equal the reference's (Vertex 32, Triangle 52, Material 44).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace fyprt_host {
+
+struct vec2 { float x = 0, y = 0; };
+struct vec3 { float x = 0, y = 0, z = 0; };
+struct mat4 { float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; };   // column-major
+
+struct Vertex { vec3 position, normal; vec2 uv; };
+struct AABB { vec3 lowerBound, upperBound, centroidPos; };
+struct Triangle { uint32_t v0, v1, v2; int materialIndex = 0; AABB aabb; };
+struct Material {
+    bool isUseAlbedoMap = false; vec3 albedo{1.0f, 0.0f, 1.0f}; uint32_t albedoMapIndex = 0xFFFFFFFFu;
+    float roughness = 1.0f, metallic = 0.0f; vec3 emissionColor; float emissionPower = 0.0f;
+};
+struct Texture { uint32_t* pixels = nullptr; uint32_t width = 0, height = 0; };
+struct Mesh { uint32_t vertexStart = 0, vertexCount = 0, indexStart = 0, indexCount = 0; int materialIndex = 0; };
+static_assert(sizeof(Vertex) == 32 && sizeof(Triangle) == 52 && sizeof(Material) == 44, "reference layouts");
+
+struct Scene {
+    std::vector<Vertex> worldVertices; std::vector<Triangle> triangles; std::vector<uint32_t> emissiveTriangles;
+    std::vector<Mesh> meshes; std::vector<Material> materials; std::vector<Texture> textures;
+    // Scene::AddNewMeshToScene (Scene.cpp:9-92) for already-world-space geometry (identity transform)
+    Mesh* AddNewMeshToScene(const std::vector<Vertex>& meshVertices, const std::vector<uint32_t>& indices, int materialIndex) {
+        Mesh mesh; mesh.vertexStart = (uint32_t)worldVertices.size(); mesh.vertexCount = (uint32_t)meshVertices.size();
+        mesh.indexStart = (uint32_t)triangles.size() * 3u; mesh.indexCount = (uint32_t)indices.size(); mesh.materialIndex = materialIndex;
+        worldVertices.insert(worldVertices.end(), meshVertices.begin(), meshVertices.end());
+        for (size_t i = 0; i + 2 < indices.size(); i += 3) {
+            Triangle t; t.v0 = mesh.vertexStart + indices[i]; t.v1 = mesh.vertexStart + indices[i + 1]; t.v2 = mesh.vertexStart + indices[i + 2];
+            t.materialIndex = materialIndex; triangles.push_back(t);
+        }
+        meshes.push_back(mesh); return &meshes.back();
+    }
+    void InitSceneEmissiveTriangles() {               // Scene.cpp:209-221
+        emissiveTriangles.clear();
+        for (uint32_t i = 0; i < triangles.size(); ++i) {
+            const Material& m = materials[triangles[i].materialIndex];
+            const float ex = m.emissionColor.x * m.emissionPower, ey = m.emissionColor.y * m.emissionPower, ez = m.emissionColor.z * m.emissionPower;
+            if (ex * ex + ey * ey + ez * ez > 0.0f) emissiveTriangles.push_back(i);
+        }
+    }
+};
+
+// Camera.h:9-83 with the matrices filled by perspectiveFov / lookAt (glm RH, [-1,1] depth) and a general 4x4 inverse.
+class Camera {
+public:
+    Camera(float verticalFOV, float nearClip, float farClip) : m_FOV(verticalFOV), m_Near(nearClip), m_Far(farClip) {}
+    void OnResize(uint32_t w, uint32_t h) {
+        if (w == m_W && h == m_H) return;
+        m_W = w; m_H = h;
+        const float rad = m_FOV * 3.14159265358979f / 180.0f, hh = std::cos(0.5f * rad) / std::sin(0.5f * rad), ww = hh * (float)h / (float)w;
+        mat4 p; for (float& v : p.m) v = 0.0f;
+        p.m[0] = ww; p.m[5] = hh; p.m[10] = -(m_Far + m_Near) / (m_Far - m_Near); p.m[11] = -1.0f; p.m[14] = -(2.0f * m_Far * m_Near) / (m_Far - m_Near);
+        m_Projection = p; m_InverseProjection = Inverse(p);
+    }
+    void SetPosition(const vec3& p) { m_Position = p; UpdateCameraView(); }
+    void SetDirection(const vec3& d) { m_Forward = d; UpdateCameraView(); }
+    void SetPrevProjection(const mat4& m) { m_PrevProjection = m; }
+    void SetPrevView(const mat4& m) { m_PrevView = m; }
+    const mat4& GetProjection() const { return m_Projection; }
+    const mat4& GetPrevProjection() const { return m_PrevProjection; }
+    const mat4& GetInverseProjection() const { return m_InverseProjection; }
+    const mat4& GetView() const { return m_View; }
+    const mat4& GetPrevView() const { return m_PrevView; }
+    const mat4& GetInverseView() const { return m_InverseView; }
+    vec3& GetPosition() { return m_Position; }
+    uint32_t GetViewportWidth() const { return m_W; }
+    uint32_t GetViewportHeight() const { return m_H; }
+private:
+    void UpdateCameraView() {                          // Camera.cpp:108-134 (lookAt towards position + forward, up = +y)
+        auto nrm = [](vec3 v) { float l = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); return vec3{v.x / l, v.y / l, v.z / l}; };
+        auto crs = [](vec3 a, vec3 b) { return vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+        auto dt = [](vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+        const vec3 f = nrm(m_Forward), s = nrm(crs(f, vec3{0, 1, 0})), u = crs(s, f);
+        mat4 v;
+        v.m[0] = s.x; v.m[4] = s.y; v.m[8] = s.z; v.m[1] = u.x; v.m[5] = u.y; v.m[9] = u.z; v.m[2] = -f.x; v.m[6] = -f.y; v.m[10] = -f.z;
+        v.m[12] = -dt(s, m_Position); v.m[13] = -dt(u, m_Position); v.m[14] = dt(f, m_Position);
+        m_View = v; m_InverseView = Inverse(v); m_PrevProjection = m_Projection; m_PrevView = m_View;
+    }
+    static mat4 Inverse(const mat4& a) {               // Gauss–Jordan in double on the column-major array
+        double m[4][8];
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { m[r][c] = a.m[c * 4 + r]; m[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+        for (int i = 0; i < 4; ++i) {
+            int p = i; for (int r = i + 1; r < 4; ++r) if (std::fabs(m[r][i]) > std::fabs(m[p][i])) p = r;
+            for (int c = 0; c < 8; ++c) std::swap(m[i][c], m[p][c]);
+            const double d = m[i][i]; for (int c = 0; c < 8; ++c) m[i][c] /= d;
+            for (int r = 0; r < 4; ++r) if (r != i) { const double f = m[r][i]; for (int c = 0; c < 8; ++c) m[r][c] -= f * m[i][c]; }
+        }
+        mat4 o; for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) o.m[c * 4 + r] = (float)m[r][4 + c];
+        return o;
+    }
+    mat4 m_Projection, m_View, m_PrevProjection, m_PrevView, m_InverseProjection, m_InverseView;
+    float m_FOV, m_Near, m_Far; vec3 m_Position{0, 0, 6}, m_Forward{0, 0, -1}; uint32_t m_W = 0, m_H = 0;
+};
+
+}  // namespace fyprt_host
