@@ -298,7 +298,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
-    auto gridFor = [&](uint32_t rb, uint32_t re) { return dim3(tilesX * ((re - rb + 15u) / 16u)); };
+    auto gridFor = [&](uint32_t rb, uint32_t re) { return dim3(((tilesX * ((re - rb + 15u) / 16u) + 7u) / 8u) * 8u); };   // padded to 8: XCD-aware tile order
     const dim3 block(kBlock);
     const dim3 grid = gridFor(c->rowBegin, c->rowEnd);
     int ei = 0;

@@ -137,6 +137,97 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     return h;
 }
 
+// Visibility query towards a known light triangle (shadow rays of ReSTIR DI Part 2, NEE and
+// light-source sampling).  The reference runs a full closest-hit TraceRay and then compares the hit
+// index with the light (R.cu:2014-2031, :1383-1403, :1501-1504); all the callers use of the result is
+//   (objectIndex == light && hitDistance >= 0) | hitDistance < 0 (nothing hit at all) | anything else.
+// So: intersect the light triangle first (same Möller–Trumbore), then traverse with the interval cut at
+// t_light and stop at the FIRST triangle closer than the light (any-hit).  If the ray misses the light
+// triangle itself (edge rounding) fall back to the full closest-hit query.  Exact-t ties count as
+// "not closer" (the reference's own tie order is traversal-order dependent).
+struct ShadowHit { float hitDistance; int32_t objectIndex; };
+RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri, int32_t* ldsBase) {
+    ShadowHit r;
+    const bool counting = sc.rayCounter != nullptr;
+    float tL = -1.0f;
+    {
+        const float4* p = sc.triPos + (size_t)lightTri * 3;
+        const float4 a = p[0], b = p[1], c = p[2];
+        const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z) - v0, e2 = mk3(c.x, c.y, c.z) - v0;
+        const f3 hh = cross(d, e2);
+        const float det = dot(e1, hh), f = 1.0f / det;
+        const f3 s = o - v0;
+        const float u = f * dot(s, hh);
+        if (!(u < 0.0f || u > 1.0f)) {
+            const f3 q = cross(s, e1);
+            const float v = f * dot(d, q);
+            if (!(v < 0.0f || (u + v) > 1.0f)) { const float t = f * dot(e2, q); if (t > 0.0001f) tL = t; }
+        }
+    }
+    if (!(tL > 0.0f)) {                               // light not hit by its own shadow ray: exact fallback
+        if (counting) atomicAdd(sc.rayCounter + 2, 1ull);
+        const Hit h = trace_closest(sc, o, d, ldsBase);
+        r.hitDistance = (h.tri < 0) ? -1.0f : h.t; r.objectIndex = h.tri;
+        return r;
+    }
+    uint32_t nBox = 0, nTri = 1;
+    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    const float cut = tL * 1.000001f;
+    Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
+    int32_t cur = sc.rootRef;
+    r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
+    bool occluded = false;
+    while (!occluded) {
+        while (cur >= 0) {
+            const float4* n = sc.nodes + (size_t)cur * 4;
+            const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            if (counting) nBox += 2;
+            float ax = (q0.x - o.x) * ix, bx = (q0.w - o.x) * ix;
+            float ay = (q0.y - o.y) * iy, by = (q1.x - o.y) * iy;
+            float az = (q0.z - o.z) * iz, bz = (q1.y - o.z) * iz;
+            const float n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+            const float f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), cut));
+            ax = (q1.z - o.x) * ix; bx = (q2.y - o.x) * ix;
+            ay = (q1.w - o.y) * iy; by = (q2.z - o.y) * iy;
+            az = (q2.x - o.z) * iz; bz = (q2.w - o.z) * iz;
+            const float n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), cut));
+            const bool h0 = n0 <= f0, h1 = n1 <= f1;
+            const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) { const bool swap = n1 < n0; st.push(swap ? c0 : c1); cur = swap ? c1 : c0; }
+            else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else cur = st.pop();
+        }
+        if (cur == kExit) break;
+        const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            const uint32_t id = (uint32_t)__float_as_int(c.y);
+            if (id == lightTri) continue;
+            if (counting) nTri += 1;
+            const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+            const f3 hh = cross(d, e2);
+            const float det = dot(e1, hh), f = 1.0f / det;
+            const f3 s = o - v0;
+            const float u = f * dot(s, hh);
+            if (u < 0.0f || u > 1.0f) continue;
+            const f3 q = cross(s, e1);
+            const float v = f * dot(d, q);
+            if (v < 0.0f || (u + v) > 1.0f) continue;
+            const float t = f * dot(e2, q);
+            if (t > 0.0001f && t < tL) { r.hitDistance = t; r.objectIndex = (int32_t)id; occluded = true; break; }
+        }
+        cur = st.pop();
+    }
+    if (counting) {
+        atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
+        atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, 1ull);
+    }
+    return r;
+}
+
 // Miss (Renderer.cu:2423-2429; worldPosition / objectIndex zero-filled / -1: DESIGN.md §5 R1)
 RT_DEV Payload make_miss() { Payload p; p.hitDistance = -1.0f; p.px = p.py = p.pz = 0.0f; p.nx = p.ny = p.nz = 0.0f; p.u = 0.0f; p.v = 0.0f; p.objectIndex = -1; return p; }
 // ClosestHit (Renderer.cu:2389-2421) from the per-triangle shading record

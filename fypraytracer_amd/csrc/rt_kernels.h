@@ -12,8 +12,15 @@ enum Tech { T_BRUTE = 0, T_UNIFORM = 1, T_COSINE = 2, T_GGX = 3, T_BRDF = 4, T_L
 
 // pixel owned by this thread: workgroup = 16x16 pixels, wave = 8x8 tile
 RT_DEV bool pixel_of_thread(const DevFrame& fr, uint32_t rowBegin, uint32_t rowEnd, uint32_t& x, uint32_t& y) {
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so give
+    // each XCD one contiguous run of screen tiles — neighbouring tiles walk the same BVH subtrees and now hit the
+    // same 4 MB L2.  The grid is padded to a multiple of 8 workgroups (speed only; any placement is correct).
     const uint32_t tilesX = (fr.W + 15u) >> 4;
-    const uint32_t bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const uint32_t tilesY = (rowEnd - rowBegin + 15u) >> 4, nTiles = tilesX * tilesY;
+    const uint32_t perXcd = gridDim.x >> 3;
+    const uint32_t tile = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
+    if (tile >= nTiles) return false;
+    const uint32_t bx = tile % tilesX, by = tile / tilesX;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     x = (bx << 4) + ((wave & 1u) << 3) + (lane & 7u);
     y = rowBegin + (by << 4) + ((wave >> 1) << 3) + (lane >> 3);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_light_source(DevScene sc, DevCamera 
         const float triAreaPDF = 1.0f / tri_area(g);
         const float totalPDF = (pl.pmf * triAreaPDF) * (dist * dist);
         const f3 T = splat3(1.0f) * (((brdf * cx) * cy) / totalPDF);
-        const Payload hit = trace_ray(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, stk);
+        const ShadowHit hit = trace_shadow(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, pl.tri, stk);
         if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; continue; }
         if ((uint32_t)hit.objectIndex != pl.tri) continue;
         const Mat lm = load_mat(sc, g.mat);
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_nee(DevScene sc, DevCamera cam, DevF
             f3 ld = lp - pos3(hit);
             const float dist = length(ld);
             ld = ld / dist;
-            const Payload sh = trace_ray(sc, pos3(hit) + nrm3(hit) * 1e-12f, ld, stk);
+            const ShadowHit sh = trace_shadow(sc, pos3(hit) + nrm3(hit) * 1e-12f, ld, pl.tri, stk);
             if (sh.hitDistance > 0.0f && (uint32_t)sh.objectIndex == pl.tri) {
                 const f3 brdf = eval_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
                 const float cx = gmax(dot(ld, nrm3(hit)), 0.0f);
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
     const float triAreaPDF = 1.0f / tri_area(g);
     const float sa = triAreaPDF * (dist * dist);
     const f3 T = ((brdf * cx) * cy) / sa;
-    const Payload hit = trace_ray(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, stk);
+    const ShadowHit hit = trace_shadow(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, ti, stk);
     f3 radiance = splat3(0.0f);
     if ((uint32_t)hit.objectIndex == ti && hit.hitDistance >= 0.0f) {
         const Mat lm = load_mat(sc, g.mat);

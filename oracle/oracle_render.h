@@ -76,7 +76,14 @@ static inline bool GI_Valid(const GIReservoir& r) { return r.M > 0 && length2(r.
 
 // ---- tracer interface (reference traversal below; the product's own traversal order is
 //      restated in oracle_product_trace.h for the instrumented byte counts)
-struct Tracer { virtual ~Tracer() {} virtual Payload Trace(const Ray& ray, Counters& c) const = 0; };
+struct Tracer {
+    virtual ~Tracer() {}
+    virtual Payload Trace(const Ray& ray, Counters& c) const = 0;
+    // Shadow query: the callers only use (objectIndex == target && hitDistance >= 0) | hitDistance < 0 | other
+    // (R.cu:2016-2031, :1386-1394, :1503-1504).  The reference answers it with a full closest-hit TraceRay — the
+    // default here; the product's early-terminating variant is restated in ProductTracer.
+    virtual Payload TraceTo(const Ray& ray, uint32_t targetTri, Counters& c) const { (void)targetTri; return Trace(ray, c); }
+};
 
 static inline bool IntersectRayAABB(const Ray& ray, const AABB& box) {          // BVH.cuh:124-165
     float tMin = 0.0f, tMax = FLT_MAX;
@@ -366,7 +373,7 @@ struct Renderer {
             float totalPDF = sl.pmf * triAreaPDF * (dist * dist);
             T *= brdf * cx * cy / totalPDF;
             Ray ray{pp.worldPosition + pp.worldNormal * 1e-12f, dir};
-            Payload hit = tracer.Trace(ray, c);
+            Payload hit = tracer.TraceTo(ray, sl.emitterIndex, c);
             if (hit.hitDistance < 0.0f) { radiance += T * st.skyColor; continue; }
             if ((uint32_t)hit.objectIndex != sl.emitterIndex) continue;
             const Material& m = sc.materials[lt.materialIndex];
@@ -403,7 +410,7 @@ struct Renderer {
                 float dist = length(ld);
                 ld /= dist;
                 Ray shadow{hit.worldPosition + hit.worldNormal * 1e-12f, ld};
-                Payload sh = tracer.Trace(shadow, c);
+                Payload sh = tracer.TraceTo(shadow, sl.emitterIndex, c);
                 if (sh.hitDistance > 0.0f && (uint32_t)sh.objectIndex == sl.emitterIndex) {
                     vec3 ln = TriNormal(n0, n1, n2);
                     vec3 brdf = CalculateBRDF(hit.worldNormal, -pathRay.direction, ld, albedo, mat.metallic, mat.roughness);
@@ -572,7 +579,7 @@ struct Renderer {
         float solidAnglePDF = triAreaPDF * (dist * dist);
         vec3 T = brdf * cx * cy / solidAnglePDF;
         Ray ray{pp.worldPosition + pp.worldNormal * 1e-12f, dir};
-        Payload hit = tracer.Trace(ray, c);
+        Payload hit = tracer.TraceTo(ray, ti, c);
         bool vis = (uint32_t)hit.objectIndex == ti;
         if (vis && hit.hitDistance >= 0.0f) {
             const Material& m = sc.materials[et.materialIndex];
@@ -724,6 +731,7 @@ struct Renderer {
             rows(h0, h1, [&](uint32_t x, uint32_t y, Counters& c) {
                 uint32_t i = x + y * W;
                 vec4 col = (tech == RESTIR_DI) ? DI_Part1(x, y, c) : GI_Part1(x, y, c);
+                if (y < y0 || y >= y1) return;                                                                           // halo rows: reservoirs only
                 if (col.x == 0.0f && col.y == 0.0f && col.z == 0.0f && col.w == 0.0f) fr.image[i] = ConvertToRGBA(col);   // sentinel :2746-2750
                 else Epilogue(i, col);
             });
