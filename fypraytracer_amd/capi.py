@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_set_camera", "fyprt_render", "fyprt_render_async", "fyprt_synchronize", "fyprt_readback",
     "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer",
     "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees",
-    "fyprt_set_ray_counting", "fyprt_version",
+    "fyprt_set_ray_counting", "fyprt_set_tuning", "fyprt_version",
 ]
 
 
@@ -168,6 +168,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_export_bvh.argtypes = [vp, vp, C.POINTER(u32), vp, C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]
     lib.fyprt_export_lighttrees.argtypes = [vp, vp, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(u32), vp, vp, vp]
     lib.fyprt_set_ray_counting.argtypes = [vp, C.c_int]
+    lib.fyprt_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     lib.fyprt_version.restype = C.c_char_p
     for f in EXPORTED_SYMBOLS:
         fn = getattr(lib, f)
@@ -320,6 +321,9 @@ class Context:
 
     def set_ray_counting(self, on: bool):
         self._check(self.lib.fyprt_set_ray_counting(self.h, 1 if on else 0))
+
+    def set_tuning(self, key: int, value: int):
+        self._check(self.lib.fyprt_set_tuning(self.h, key, value))
 
     def export_bvh(self):
         nn, nt, root, depth = C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_uint32()

@@ -57,6 +57,7 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
+    int tuning[8] = {2, 0, 0, 0, 0, 0, 0, 0};   // [0] tile order
 
     int fail(int code, const std::string& m) { err = m; return code; }
     int hip(hipError_t e, const char* what) {
@@ -298,7 +299,12 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
-    auto gridFor = [&](uint32_t rb, uint32_t re) { return dim3(((tilesX * ((re - rb + 15u) / 16u) + 7u) / 8u) * 8u); };   // padded to 8: XCD-aware tile order
+    fr.tileOrder = (uint32_t)c->tuning[0];
+    auto gridFor = [&](uint32_t rb, uint32_t re) {
+        const uint32_t tilesY = (re - rb + 15u) / 16u;
+        if (c->tuning[0] == 2) return dim3(tilesX * ((tilesY + 7u) / 8u) * 8u);
+        return dim3(((tilesX * tilesY + 7u) / 8u) * 8u);
+    };
     const dim3 block(kBlock);
     const dim3 grid = gridFor(c->rowBegin, c->rowEnd);
     int ei = 0;
@@ -427,6 +433,12 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
     if (blas_first) std::memcpy(blas_first, l.first.data(), l.first.size() * 4);
     if (blas_count) std::memcpy(blas_count, l.count.data(), l.count.size() * 4);
     if (blas_root) std::memcpy(blas_root, l.root.data(), l.root.size() * 4);
+    return FYPRT_OK;
+}
+
+int fyprt_set_tuning(fyprt_context* c, int key, int value) {
+    if (!c || key < 0 || key >= 8) return FYPRT_EINVAL;
+    c->tuning[key] = value;
     return FYPRT_OK;
 }
 

@@ -12,15 +12,26 @@ enum Tech { T_BRUTE = 0, T_UNIFORM = 1, T_COSINE = 2, T_GGX = 3, T_BRDF = 4, T_L
 
 // pixel owned by this thread: workgroup = 16x16 pixels, wave = 8x8 tile
 RT_DEV bool pixel_of_thread(const DevFrame& fr, uint32_t rowBegin, uint32_t rowEnd, uint32_t& x, uint32_t& y) {
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so give
-    // each XCD one contiguous run of screen tiles — neighbouring tiles walk the same BVH subtrees and now hit the
-    // same 4 MB L2.  The grid is padded to a multiple of 8 workgroups (speed only; any placement is correct).
+    // Tile order (speed only; any placement is correct).  Workgroups are dealt round-robin over the 8 XCDs
+    // (blockIdx % 8 share an L2).  0: linear.  1: each XCD gets one contiguous eighth of the tiles.
+    // 2: each XCD gets every 8th ROW of tiles (L2 locality along a row, load balance down the image).
+    // The grid is padded so every XCD owns the same number of workgroups.
     const uint32_t tilesX = (fr.W + 15u) >> 4;
     const uint32_t tilesY = (rowEnd - rowBegin + 15u) >> 4, nTiles = tilesX * tilesY;
-    const uint32_t perXcd = gridDim.x >> 3;
-    const uint32_t tile = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
-    if (tile >= nTiles) return false;
-    const uint32_t bx = tile % tilesX, by = tile / tilesX;
+    uint32_t bx, by;
+    if (fr.tileOrder == 1u) {
+        const uint32_t perXcd = gridDim.x >> 3;
+        const uint32_t tile = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
+        if (tile >= nTiles) return false;
+        bx = tile % tilesX; by = tile / tilesX;
+    } else if (fr.tileOrder == 2u) {
+        const uint32_t idx = blockIdx.x >> 3;
+        bx = idx % tilesX; by = (idx / tilesX) * 8u + (blockIdx.x & 7u);
+        if (by >= tilesY) return false;
+    } else {
+        if (blockIdx.x >= nTiles) return false;
+        bx = blockIdx.x % tilesX; by = blockIdx.x / tilesX;
+    }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     x = (bx << 4) + ((wave & 1u) << 3) + (lane & 7u);
     y = rowBegin + (by << 4) + ((wave >> 1) << 3) + (lane >> 3);

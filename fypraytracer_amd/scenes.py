@@ -71,11 +71,19 @@ def cornell_box(light_power=40.0):
     return sc
 
 
-def cornell_camera(width, height):
+def cornell_camera(width, height, off_axis=False):
+    """BASELINE config 1 camera: fov 45, (0,0,3.4) looking down -z.  `off_axis=True` nudges the pose so that rays
+    through pixel corners no longer hit quad diagonals / wall seams exactly (equal-t ties, whose winner is
+    traversal-order dependent in the reference itself) — used by the golden fixtures."""
     cam = Camera(45.0, 0.1, 100.0)                     # WalnutApp.cpp:44
     cam.on_resize(width, height)
-    cam.forward = np.array([0, 0, -1], dtype=F)
-    cam.set_position((0.0, 0.0, 3.4))
+    if off_axis:
+        d = np.array([0.0171, -0.0093, -1.0], dtype=np.float64)
+        cam.forward = (d / np.linalg.norm(d)).astype(F)
+        cam.set_position((0.0137, 0.0071, 3.4))
+    else:
+        cam.forward = np.array([0, 0, -1], dtype=F)
+        cam.set_position((0.0, 0.0, 3.4))
     return cam
 
 

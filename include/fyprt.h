@@ -226,6 +226,10 @@ int fyprt_export_lighttrees(fyprt_context* ctx, fyprt_lighttree_node* tlas, uint
 /* Count rays / box tests / triangle tests on the device (atomics; slows the frame); off by default. */
 int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
 
+/* Performance knobs that never change results (A/B experiments; defaults are the measured best).
+ * key 0: tile order — 0 linear, 1 one contiguous eighth of the tiles per XCD, 2 every 8th tile row per XCD. */
+int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
+
 /* Library / build identification ("fyprt <version> gfx950 ..."). */
 const char* fyprt_version(void);
 

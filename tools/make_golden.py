@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the CPU oracle (reference-order traversal, deterministic
 transcendentals).  The reference ships no golden vectors, so these fixtures are the pin:
-Cornell box 64x64 (BASELINE config 1 geometry), every technique, frames 1-3 accumulated.
+Cornell box 64x64 (BASELINE config 1 geometry, camera nudged off-axis to avoid exact-t ties), every technique, frames 1-3 accumulated.
 Each file: inputs (settings as a dict) + expected outputs (RGBA8 per frame, float4 accumulation after
 frame 3, and for the ReSTIR techniques the hit payloads and reservoirs after frame 3)."""
 import sys
@@ -25,7 +25,7 @@ def main():
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
     sc = scenes.cornell_box()
-    cam = scenes.cornell_camera(W, H)
+    cam = scenes.cornell_camera(W, H, off_axis=True)
     for tech in range(9):
         o = Oracle(sc, W, H)
         o.set_camera(cam)

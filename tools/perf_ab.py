@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of result-neutral tuning knobs in ONE process (cdna guide §5.4 rule 24):
+N variants x M rounds on the bench workload, median / min of the per-kernel hipEvent times."""
+import argparse
+import itertools
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from fypraytracer_amd import capi, scenes  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--key", type=int, default=0)
+    ap.add_argument("--values", type=int, nargs="+", default=[0, 1, 2])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--technique", type=int, default=7)
+    ap.add_argument("--scene", default="hall")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    a = ap.parse_args()
+    W, H = a.width, a.height
+    sc = scenes.hall_scene() if a.scene == "hall" else scenes.hall_scene_small()
+    cam = scenes.hall_camera(W, H)
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.upload_scene(sc)
+    ctx.set_camera(cam)
+    st = capi.Settings(technique=a.technique, light_bounces=2 if a.technique != 7 else 1, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
+    res = {v: [] for v in a.values}
+    for r in range(a.rounds):
+        for v in a.values:
+            ctx.set_tuning(a.key, v)
+            ctx.reset_frame_index()
+            parts = []
+            for f in range(a.frames):
+                st.rand_seed = f + 1
+                s = ctx.render(st)
+                if f >= 2:
+                    parts.append(list(s.kernel_ms_part)[:2])
+            res[v].append(np.median(np.array(parts), axis=0))
+    for v in a.values:
+        m = np.array(res[v])
+        print(json.dumps({"key": a.key, "value": v, "p1_ms_median": round(float(np.median(m[:, 0])), 4), "p2_ms_median": round(float(np.median(m[:, 1])), 4),
+                          "p1_ms_min": round(float(m[:, 0].min()), 4), "p2_ms_min": round(float(m[:, 1].min()), 4),
+                          "total_median": round(float(np.median(m.sum(1))), 4)}))
+
+
+if __name__ == "__main__":
+    main()
