@@ -26,7 +26,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL_NAMES = {7: ["k_di_part1", "k_di_part2"], 8: ["k_gi_part1", "k_gi_part2"]}
+KERNEL_NAMES = {7: ["k_di_part1", "k_di_part2_setup", "k_di_part2_trace"], 8: ["k_gi_part1", "k_gi_part2"]}
 
 
 def streaming_bytes(tech, pixels_p1, finished_p1, pixels_p2, skipped_p2, neighbors):
@@ -173,13 +173,17 @@ def main():
         pixels_band = (r1 - r0) * W
         if restir:
             if tech == 7:
-                p2_pixels = int(cs.part_rays[1])                       # DI: exactly one shadow ray per Part-2 pixel
+                p2_pixels = int(cs.part_rays[2])                       # DI: exactly one shadow ray per Part-2 pixel (trace launch)
             else:
                 p2_pixels = int(np.count_nonzero(ctx.read_buffer(capi.BUF_GI)["M"].reshape(H, W)[r0:r1]))
             p1_pixels = p1_rows * W
             finished = p1_pixels - p2_pixels if N == 1 else max(0, pixels_band - p2_pixels)
             sb1, sb2 = streaming_bytes(tech, p1_pixels, finished, p2_pixels, pixels_band - p2_pixels, st.spatial_neighbor_num)
-            stream_b = [sb1, sb2]
+            if tech == 7:   # Part 2 split: setup streams the per-pixel state and writes a 64-byte task; trace reads it and does accum/image
+                trace_b = p2_pixels * (64 + 32 + 4)
+                stream_b = [sb1, sb2 - p2_pixels * (32 + 4) + p2_pixels * 64, trace_b]
+            else:
+                stream_b = [sb1, sb2]
         else:
             stream_b = [pixels_band * 48]
         alg = []

@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 #include "rt_host.h"
-#include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 using namespace rt;
 
@@ -43,7 +43,7 @@ void matmul_cm(const float* a, const float* b, float* out) {
 
 struct fyprt_context {
     int device = 0; hipStream_t stream = nullptr; std::string err; bool hostOnly = false;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
     bool haveScene = false, haveCamera = false, countRays = false;
     // per-pixel buffers
@@ -57,7 +57,9 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[8] = {2, 0, 0, 0, 0, 0, 0, 0};   // [0] tile order
+    int tuning[8] = {2, 1, 6, 0, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int numCUs = 256;
+    DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters;
 
     int fail(int code, const std::string& m) { err = m; return code; }
     int hip(hipError_t e, const char* what) {
@@ -90,6 +92,8 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
+    (void)c->queueCounters.alloc(4);
     (void)c->rayCounter.alloc(16);
     (void)hipMemset(c->rayCounter.p, 0, 128);
     *out = c;
@@ -106,7 +110,7 @@ void fyprt_destroy(fyprt_context* c) {
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
-    c->rayCounter.release();
+    c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -124,6 +128,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
     HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
     HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n));
+    HIPCHK(c, c->shadowTasks.alloc(n * 4));
     // cudaMemset(…, 0, …) of every buffer: Renderer.cu:333-355, :372, :393, :414
     HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->image.p, 0, c->image.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->payload.p, 0, c->payload.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->depth.p, 0, c->depth.bytes(), c->stream));
@@ -326,9 +331,19 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             else hipLaunchKernelGGL(k_gi_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
-            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
-            else hipLaunchKernelGGL(k_gi_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
             launches = 2;
+            if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
+                ShadowQueue q{c->shadowTasks.p, c->queueCounters.p};
+                HIPCHK(c, hipMemsetAsync(c->queueCounters.p, 0, 16, c->stream));
+                hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st, q);
+                if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+                if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;
+                const int perCU = c->tuning[2] > 0 ? c->tuning[2] : 6;
+                hipLaunchKernelGGL(k_di_part2_trace, dim3((uint32_t)(c->numCUs * perCU)), block, 0, c->stream, c->dsc, fr, q);
+                launches = 3;
+            }
+            else if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
+            else hipLaunchKernelGGL(k_gi_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
             c->normalFlip = !c->normalFlip;
             break;
         }

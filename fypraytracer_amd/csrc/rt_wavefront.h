@@ -1,0 +1,228 @@
+// ReSTIR DI Part 2 as a two-stage wavefront (the north-star's "wavefront ballot / prefix-sum ray compaction and
+// persistent-thread work stealing"):
+//
+//   k_di_part2_setup  one thread per pixel: spatial reuse, light-point sample, BRDF — everything of
+//                     PerPixel_ReSTIR_DI_Part2 (R.cu:1875-2007, :2033-2038) except the shadow ray; live pixels
+//                     append one 64-byte shadow task to a queue (wave ballot + prefix popcount, one atomic per wave).
+//   k_di_part2_trace  persistent waves: every lane owns one in-flight shadow ray; when >= kRefillLanes lanes of a wave
+//                     have finished, the wave steals the next tasks from the queue head (one atomic per refill) and
+//                     refills exactly those lanes, so SIMD lanes stay busy although shadow rays differ 10x in length
+//                     (measured lane utilisation of the one-thread-per-pixel Part 2: 35 %).  A finished lane runs the
+//                     fused epilogue for its pixel (visibility select, accumulate, tonemap, pack) and goes idle.
+//
+// Same arithmetic, same per-ray traversal (trace_shadow of rt_device.h, incl. the closest-hit fallback), so every
+// output bit and every instrumentation count is unchanged — only the mapping of rays to lanes differs.
+#pragma once
+#include "rt_kernels.h"
+
+namespace rt {
+
+struct ShadowQueue { float4* tasks; uint32_t* counters; };   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
+constexpr int kRefillLanes = 16;
+
+__global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
+    uint32_t x, y;
+    const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
+    const uint32_t i = x + y * fr.W;
+    bool live = inside && fr.image[i] == 0u;                          // Renderer.cu:2787
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = 0;
+    if (live) {
+        uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
+        DIRes R = fr.di[i];
+        const Payload pp = fr.payload[i];
+        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        const f3 pd = ray_direction(cam, x, y);
+        if (st.useSpatial) {
+            uint32_t Z = 0; DIRes S = di_empty();
+            { const float pdf = R.pdf; di_update(S, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
+            for (uint32_t n = 0; n < st.numNeighbors; ++n) {
+                const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+                const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
+                if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906) continue;
+                const DIRes N = fr.di[ni];
+                const float pdf = N.pdf;
+                di_update(S, N.index, (pdf * N.W) * (float)N.M, N.M, pdf, seed);
+                Z += pdf > 0.0f ? N.M : 0u;
+            }
+            const float m = 1.0f / (float)Z;
+            S.W = S.pdf > 0.0f ? (1.0f / S.pdf) * (m * S.wSum) : 0.0f;
+            R = S;
+        }
+        ti = sc.emissive[R.index];
+        const TriGeom g = load_tri(sc, ti);
+        const f3 ep = tri_random_point(g, seed);
+        f3 dir = ep - pos3(pp);
+        const float dist = length(pos3(pp) - ep);
+        dir = dir / dist;
+        const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+        const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
+        const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
+        const float triAreaPDF = 1.0f / tri_area(g);
+        const float sa = triAreaPDF * (dist * dist);
+        const f3 T = ((brdf * cx) * cy) / sa;
+        const Mat lm = load_mat(sc, g.mat);
+        if (length(emission(lm)) > 0.0f) { Lvis = T * emission(lm); Lvis = Lvis * R.W; }       // R.cu:2018-2027
+        Lsky = T * st.sky;                                                                     // R.cu:2028-2031
+        ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
+        fr.depth[i] = pp.hitDistance;
+        fr.diPrev[i] = R;
+    }
+    // ---- wave-level compaction of the live lanes into the task queue
+    const unsigned long long mask = __ballot(live);
+    if (mask == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(q.counters + 0, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, __builtin_ctzll(mask));
+    if (live) {
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        float4* t = q.tasks + (size_t)slot * 4;
+        t[0] = make_float4(ro.x, ro.y, ro.z, __int_as_float((int)i));
+        t[1] = make_float4(rd.x, rd.y, rd.z, __int_as_float((int)ti));
+        t[2] = make_float4(Lvis.x, Lvis.y, Lvis.z, 0.0f);
+        t[3] = make_float4(Lsky.x, Lsky.y, Lsky.z, 0.0f);
+    }
+}
+
+// per-lane in-flight ray of the persistent trace kernel
+struct LaneRay {
+    f3 o, d; float ix, iy, iz; float tL, cut; uint32_t lightTri, pixel; f3 Lvis, Lsky;
+    int32_t cur; int top; int32_t hitTri; bool closestMode; uint32_t nBox, nTri;
+};
+
+template <int LDS_N>
+RT_DEV void lane_push(int32_t* lds, int32_t* spill, int& top, int32_t v) { if (top < LDS_N) lds[top * kBlock] = v; else spill[top - LDS_N] = v; ++top; }
+template <int LDS_N>
+RT_DEV int32_t lane_pop(int32_t* lds, int32_t* spill, int& top) { --top; return (top < LDS_N) ? lds[top * kBlock] : spill[top - LDS_N]; }
+
+constexpr int kTraceLds = 16;
+
+__global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame fr, ShadowQueue q) {
+    __shared__ int32_t s_stack[kTraceLds * kBlock];
+    int32_t* lds = s_stack + threadIdx.x;
+    int32_t spill[kLdsStack + kSpillStack - kTraceLds];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = q.counters[0];
+    const bool counting = sc.rayCounter != nullptr;
+    LaneRay r; r.cur = kExit; r.top = 0;
+    bool active = false;
+    bool more = true;                                              // wave-uniform: queue not yet exhausted
+    while (true) {
+        // ---------------- refill: idle lanes steal the next tasks
+        const unsigned long long idle = __ballot(!active);
+        if (more && (uint32_t)__popcll(idle) >= (uint32_t)kRefillLanes) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(q.counters + 1, (uint32_t)__popcll(idle));
+            base = (uint32_t)__shfl((int)base, __builtin_ctzll(idle));
+            more = base + (uint32_t)__popcll(idle) < total;
+            const uint32_t slot = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && slot < total) {
+                const float4* t = q.tasks + (size_t)slot * 4;
+                const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+                r.o = mk3(t0.x, t0.y, t0.z); r.pixel = (uint32_t)__float_as_int(t0.w);
+                r.d = mk3(t1.x, t1.y, t1.z); r.lightTri = (uint32_t)__float_as_int(t1.w);
+                r.Lvis = mk3(t2.x, t2.y, t2.z); r.Lsky = mk3(t3.x, t3.y, t3.z);
+                r.ix = safe_inv(r.d.x); r.iy = safe_inv(r.d.y); r.iz = safe_inv(r.d.z);
+                // light triangle first (same Möller–Trumbore as trace_shadow)
+                float tL = -1.0f;
+                {
+                    const float4* p = sc.triPos + (size_t)r.lightTri * 3;
+                    const float4 a = p[0], b = p[1], c = p[2];
+                    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z) - v0, e2 = mk3(c.x, c.y, c.z) - v0;
+                    const f3 hh = cross(r.d, e2);
+                    const float det = dot(e1, hh), f = 1.0f / det;
+                    const f3 s = r.o - v0;
+                    const float u = f * dot(s, hh);
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        const f3 qq = cross(s, e1);
+                        const float v = f * dot(r.d, qq);
+                        if (!(v < 0.0f || (u + v) > 1.0f)) { const float tt = f * dot(e2, qq); if (tt > 0.0001f) tL = tt; }
+                    }
+                }
+                r.closestMode = !(tL > 0.0f);
+                r.tL = r.closestMode ? 3.402823466e+38f : tL;
+                r.cut = r.tL * 1.000001f;
+                r.hitTri = r.closestMode ? -1 : (int32_t)r.lightTri;
+                r.nBox = 0; r.nTri = 1;
+                r.top = 0; lane_push<kTraceLds>(lds, spill, r.top, kExit);
+                r.cur = (sc.triCount == 0) ? kExit : sc.rootRef;
+                active = true;
+            }
+        }
+        if (__ballot(active) == 0ull) { if (!more) break; else continue; }
+        // ---------------- traverse until enough lanes have finished to make a refill worthwhile
+        while (true) {
+            // inner nodes
+            while (active && r.cur >= 0) {
+                const float4* n = sc.nodes + (size_t)r.cur * 4;
+                const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                if (counting) r.nBox += 2;
+                float ax = (q0.x - r.o.x) * r.ix, bx = (q0.w - r.o.x) * r.ix;
+                float ay = (q0.y - r.o.y) * r.iy, by = (q1.x - r.o.y) * r.iy;
+                float az = (q0.z - r.o.z) * r.iz, bz = (q1.y - r.o.z) * r.iz;
+                const float n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+                const float f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), r.cut));
+                ax = (q1.z - r.o.x) * r.ix; bx = (q2.y - r.o.x) * r.ix;
+                ay = (q1.w - r.o.y) * r.iy; by = (q2.z - r.o.y) * r.iy;
+                az = (q2.x - r.o.z) * r.iz; bz = (q2.w - r.o.z) * r.iz;
+                const float n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+                const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), r.cut));
+                const bool h0 = n0 <= f0, h1 = n1 <= f1;
+                const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                if (h0 && h1) { const bool swap = n1 < n0; lane_push<kTraceLds>(lds, spill, r.top, swap ? c0 : c1); r.cur = swap ? c1 : c0; }
+                else if (h0) r.cur = c0;
+                else if (h1) r.cur = c1;
+                else r.cur = lane_pop<kTraceLds>(lds, spill, r.top);
+            }
+            // leaves
+            if (active && r.cur != kExit) {
+                const uint32_t code = (uint32_t)~r.cur, first = code >> 2, cnt = (code & 3u) + 1u;
+                bool occluded = false;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    const uint32_t id = (uint32_t)__float_as_int(c.y);
+                    if (!r.closestMode && id == r.lightTri) continue;
+                    if (counting) r.nTri += 1;
+                    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+                    const f3 hh = cross(r.d, e2);
+                    const float det = dot(e1, hh), f = 1.0f / det;
+                    const f3 s = r.o - v0;
+                    const float u = f * dot(s, hh);
+                    if (u < 0.0f || u > 1.0f) continue;
+                    const f3 qq = cross(s, e1);
+                    const float v = f * dot(r.d, qq);
+                    if (v < 0.0f || (u + v) > 1.0f) continue;
+                    const float t = f * dot(e2, qq);
+                    if (t > 0.0001f && t < r.tL) {
+                        r.hitTri = (int32_t)id;
+                        if (r.closestMode) { r.tL = t; r.cut = t * 1.000001f; }
+                        else { occluded = true; break; }
+                    }
+                }
+                r.cur = occluded ? kExit : lane_pop<kTraceLds>(lds, spill, r.top);
+            }
+            // finished lanes: fused epilogue for their pixel
+            if (active && r.cur == kExit) {
+                // shadow mode: hitTri == lightTri -> visible, else occluded.  closest-hit fallback: -1 -> nothing hit (sky), else occluded
+                f3 radiance = splat3(0.0f);
+                if (r.hitTri == (int32_t)r.lightTri) radiance = r.Lvis;          // R.cu:2016-2027
+                else if (r.closestMode && r.hitTri < 0) radiance = r.Lsky;       // R.cu:2028-2031
+                epilogue(fr, r.pixel, rgb1(radiance));
+                if (counting) {
+                    // same totals as trace_shadow: the fallback counts its light test, then a full closest-hit ray
+                    atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)r.nBox);
+                    atomicAdd(sc.rayCounter + 2, (unsigned long long)r.nTri);
+                    atomicAdd(sc.rayCounter + 3, (unsigned long long)((r.closestMode && r.hitTri < 0) ? 0 : 1));
+                }
+                active = false;
+            }
+            const unsigned long long act = __ballot(active);
+            if (act == 0ull) break;
+            if (more && (64u - (uint32_t)__popcll(act)) >= (uint32_t)kRefillLanes) break;
+        }
+    }
+}
+
+}  // namespace rt

@@ -227,7 +227,9 @@ int fyprt_export_lighttrees(fyprt_context* ctx, fyprt_lighttree_node* tlas, uint
 int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
 
 /* Performance knobs that never change results (A/B experiments; defaults are the measured best).
- * key 0: tile order — 0 linear, 1 one contiguous eighth of the tiles per XCD, 2 every 8th tile row per XCD. */
+ * key 0: tile order — 0 linear, 1 one contiguous eighth of the tiles per XCD, 2 every 8th tile row per XCD.
+ * key 1: ReSTIR DI Part 2 — 0 one thread per pixel, 1 setup kernel + shadow-task queue + persistent trace waves.
+ * key 2: persistent workgroups per CU for the trace kernel (default 6). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 
 /* Library / build identification ("fyprt <version> gfx950 ..."). */

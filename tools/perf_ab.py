@@ -43,7 +43,7 @@ def main():
                 st.rand_seed = f + 1
                 s = ctx.render(st)
                 if f >= 2:
-                    parts.append(list(s.kernel_ms_part)[:2])
+                    parts.append([s.kernel_ms_part[0], sum(list(s.kernel_ms_part)[1:])])
             res[v].append(np.median(np.array(parts), axis=0))
     for v in a.values:
         m = np.array(res[v])
