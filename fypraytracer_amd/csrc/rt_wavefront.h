@@ -19,6 +19,7 @@ namespace rt {
 
 struct ShadowQueue { float4* tasks; uint32_t* counters; };   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
 constexpr int kRefillLanes = 16;
+constexpr uint32_t kChunk = 128;      // tasks a wave claims per atomic (a single queue-head word saturates near 88 dequeues/us)
 
 __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
     uint32_t x, y;
@@ -107,17 +108,24 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     const bool counting = sc.rayCounter != nullptr;
     LaneRay r; r.cur = kExit; r.top = 0;
     bool active = false;
-    bool more = true;                                              // wave-uniform: queue not yet exhausted
+    bool more = true;                                              // wave-uniform: tasks may remain (in the queue or in this wave's chunk)
+    uint32_t chunkNext = 0, chunkEnd = 0;                          // wave-uniform: this wave's claimed range of the queue
     while (true) {
-        // ---------------- refill: idle lanes steal the next tasks
+        // ---------------- refill: idle lanes take the next tasks of the wave's chunk; a new chunk is stolen from the queue head when it runs dry
         const unsigned long long idle = __ballot(!active);
         if (more && (uint32_t)__popcll(idle) >= (uint32_t)kRefillLanes) {
-            uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(q.counters + 1, (uint32_t)__popcll(idle));
-            base = (uint32_t)__shfl((int)base, __builtin_ctzll(idle));
-            more = base + (uint32_t)__popcll(idle) < total;
-            const uint32_t slot = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && slot < total) {
+            if (chunkNext >= chunkEnd) {
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(q.counters + 1, kChunk);
+                base = (uint32_t)__shfl((int)base, 0);
+                chunkNext = base < total ? base : total;
+                chunkEnd = (base + kChunk < total) ? base + kChunk : total;
+            }
+            const uint32_t slot = chunkNext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t want = (uint32_t)__popcll(idle), avail = chunkEnd - chunkNext;
+            chunkNext += (want < avail) ? want : avail;
+            more = chunkNext < chunkEnd || chunkEnd < total;
+            if (!active && slot < chunkEnd) {
                 const float4* t = q.tasks + (size_t)slot * 4;
                 const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
                 r.o = mk3(t0.x, t0.y, t0.z); r.pixel = (uint32_t)__float_as_int(t0.w);
