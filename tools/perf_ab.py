@@ -34,6 +34,7 @@ def main():
     ctx.set_camera(cam)
     st = capi.Settings(technique=a.technique, light_bounces=2 if a.technique != 7 else 1, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
     res = {v: [] for v in a.values}
+    allparts = {}
     for r in range(a.rounds):
         for v in a.values:
             ctx.set_tuning(a.key, v)
@@ -45,11 +46,13 @@ def main():
                 if f >= 2:
                     parts.append([s.kernel_ms_part[0], sum(list(s.kernel_ms_part)[1:])])
             res[v].append(np.median(np.array(parts), axis=0))
+            allparts.setdefault(v, []).append(list(s.kernel_ms_part))
     for v in a.values:
         m = np.array(res[v])
         print(json.dumps({"key": a.key, "value": v, "p1_ms_median": round(float(np.median(m[:, 0])), 4), "p2_ms_median": round(float(np.median(m[:, 1])), 4),
                           "p1_ms_min": round(float(m[:, 0].min()), 4), "p2_ms_min": round(float(m[:, 1].min()), 4),
-                          "total_median": round(float(np.median(m.sum(1))), 4)}))
+                          "total_median": round(float(np.median(m.sum(1))), 4),
+                          "last_frame_parts_ms": [round(x, 4) for x in np.median(np.array(allparts[v]), axis=0)]}))
 
 
 if __name__ == "__main__":
