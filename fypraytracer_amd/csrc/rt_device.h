@@ -40,7 +40,7 @@ static_assert(sizeof(Payload) == 40 && sizeof(DIRes) == 20 && sizeof(GIRes) == 7
 struct DevFrame {
     float4* accum; uint32_t* image; Payload* payload; float* depth; f2* normalPrev; f2* normalCur;
     DIRes* di; DIRes* diPrev; GIRes* gi; GIRes* giPrev;
-    uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder;
+    uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder, sortByLight;
 };
 
 struct DevSettings {   // RenderingSettings.h:5-22 with the kernel-side uint8 casts already applied

@@ -83,10 +83,35 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         s_base = n ? atomicAdd(q.counters + 0, n) : 0u;
     }
     __syncthreads();
+    // optional: order the workgroup's tasks by light (counting sort in LDS) so that neighbouring lanes of the trace
+    // kernel aim at the same light — coherent shadow rays share their BVH path near the light
+    __shared__ uint32_t s_hist[256];
+    uint32_t rankInBucket = 0; const uint32_t key = ti & 255u;
+    if (fr.sortByLight) {
+        s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        if (live) rankInBucket = atomicAdd(&s_hist[key], 1u);
+        __syncthreads();
+        // exclusive prefix over the 256 bins (Hillis–Steele, 8 steps)
+        uint32_t v = s_hist[threadIdx.x];
+        const uint32_t own = v;
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t add = (threadIdx.x >= d) ? s_hist[threadIdx.x - d] : 0u;
+            __syncthreads();
+            v += add; s_hist[threadIdx.x] = v;
+            __syncthreads();
+        }
+        s_hist[threadIdx.x] = v - own;
+        __syncthreads();
+    }
     if (live) {
         uint32_t base = s_base;
-        for (uint32_t k = 0; k < wave; ++k) base += s_count[k];
-        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        uint32_t slot;
+        if (fr.sortByLight) slot = base + s_hist[key] + rankInBucket;
+        else {
+            for (uint32_t k = 0; k < wave; ++k) base += s_count[k];
+            slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        }
         float4* t = q.tasks + (size_t)slot * 4;
         t[0] = make_float4(ro.x, ro.y, ro.z, __int_as_float((int)i));
         t[1] = make_float4(rd.x, rd.y, rd.z, __int_as_float((int)ti));
