@@ -52,7 +52,7 @@ struct fyprt_context {
     uint32_t* externalImage = nullptr;
     // scene
     DevBuf<float4> nodes, leafTris, triPos, triShade, mats; DevBuf<DevTexture> texTable; std::vector<DevBuf<uint32_t>> texPixels;
-    DevBuf<uint32_t> emissive; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot;
+    DevBuf<uint32_t> emissive; DevBuf<float4> lightRecs; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot;
     DevBuf<unsigned long long> rayCounter;
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
@@ -109,7 +109,7 @@ void fyprt_destroy(fyprt_context* c) {
     c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release();
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
     for (auto& t : c->texPixels) t.release();
-    c->emissive.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
+    c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
     c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -260,7 +260,15 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     d.emissive = c->emissive.p; d.emissiveCount = (uint32_t)em.size();
     d.ltTlas = c->ltTlas.p; d.ltTlasCount = (uint32_t)lt.tlas.size(); d.ltTlasRoot = lt.tlasRoot;
     d.ltBlas = c->ltBlas.p; d.ltFirst = c->ltFirst.p; d.ltCount = c->ltCount.p; d.ltRoot = c->ltRoot.p;
-    d.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
+    d.rayCounter = nullptr;
+    // per-light records for ReSTIR DI, computed on the device with the kernels' own arithmetic
+    HIPCHK(c, c->lightRecs.alloc(em.size() * 3));
+    d.lightRecs = c->lightRecs.p;
+    if (!c->hostOnly && !em.empty()) {
+        hipLaunchKernelGGL(k_build_light_records, dim3(((uint32_t)em.size() + 255u) / 256u), dim3(256), 0, c->stream, d, c->lightRecs.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->haveScene = true;
     return FYPRT_OK;
 }

@@ -23,7 +23,7 @@ struct DevScene {
     const float4* nodes; const float4* leafTris; int32_t rootRef; uint32_t triCount;
     const float4* triPos; const float4* triShade; const float4* mats;
     const DevTexture* textures; uint32_t textureCount;
-    const uint32_t* emissive; uint32_t emissiveCount;
+    const uint32_t* emissive; uint32_t emissiveCount; const float4* lightRecs;
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
     const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot;
     unsigned long long* rayCounter;   // nullptr = counting off; else [0] rays [1] box tests [2] triangle tests [3] hits

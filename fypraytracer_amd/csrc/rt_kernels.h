@@ -311,18 +311,34 @@ RT_DEV bool di_update(DIRes& r, uint32_t cand, float w, uint32_t count, float pd
 }
 RT_DEV DIRes di_empty() { DIRes r; r.index = 0; r.W = 0.0f; r.pdf = 0.0f; r.wSum = 0.0f; r.M = 0; return r; }
 // unshadowed target at the light centroid (Renderer.cu:1680-1730, :1799-1849)
+// Per-emissive-slot light record, built once per scene upload ON THE DEVICE with the very expressions the reference
+// evaluates per candidate (centroid Triangle.cuh:14-18, normal :36-43, 1/area :45-51, GetEmission Material.cu:5-8), so
+// using it is bit-identical to recomputing — it removes the emissive[] -> triangle -> 3 vertices -> material gather
+// chain (R.cu:1681-1688, :1722) and ~40 ALU ops from each of the 4+1 target evaluations per pixel.
+//   q0 = centroid.xyz, 1/area | q1 = normal.xyz, triangle index | q2 = emission.xyz, 0
+__global__ void k_build_light_records(DevScene sc, float4* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sc.emissiveCount) return;
+    const uint32_t tri = sc.emissive[k];
+    const TriGeom g = load_tri(sc, tri);
+    const f3 c = tri_centroid(g), n = tri_normal(g), em = emission(load_mat(sc, g.mat));
+    out[3 * k + 0] = make_float4(c.x, c.y, c.z, 1.0f / tri_area(g));
+    out[3 * k + 1] = make_float4(n.x, n.y, n.z, __int_as_float((int)tri));
+    out[3 * k + 2] = make_float4(em.x, em.y, em.z, 0.0f);
+}
+// unshadowed target at the light centroid (Renderer.cu:1680-1730, :1799-1849)
 RT_DEV float di_target(const DevScene& sc, uint32_t emissiveSlot, const Payload& pp, f3 pd, const Mat& hm, f3 albedo) {
-    const TriGeom g = load_tri(sc, sc.emissive[emissiveSlot]);
-    const f3 ep = tri_centroid(g);
+    const float4* L = sc.lightRecs + (size_t)emissiveSlot * 3;
+    const float4 l0 = L[0], l1 = L[1], l2 = L[2];
+    const f3 ep = mk3(l0.x, l0.y, l0.z);
     f3 dir = ep - pos3(pp);
     const float dist = length(pos3(pp) - ep);
     dir = dir / dist;
     const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
     const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
-    const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
-    const float triAreaPDF = 1.0f / tri_area(g);
-    const float sa = triAreaPDF * (dist * dist);
-    const f3 Lr = (((brdf * cx) * cy) / sa) * emission(load_mat(sc, g.mat));
+    const float cy = gmax(dot(-dir, mk3(l1.x, l1.y, l1.z)), 0.0f);
+    const float sa = l0.w * (dist * dist);
+    const f3 Lr = (((brdf * cx) * cy) / sa) * mk3(l2.x, l2.y, l2.z);
     return length(Lr);
 }
 RT_DEV int f2i_sat(float f) { if (!(f == f)) return 0; if (f >= 2147483520.0f) return 2147483647; if (f <= -2147483648.0f) return (-2147483647 - 1); return (int)f; }

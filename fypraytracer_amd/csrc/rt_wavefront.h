@@ -38,9 +38,12 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
             { const float pdf = R.pdf; di_update(S, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
             for (uint32_t n = 0; n < st.numNeighbors; ++n) {
                 const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+                // all three gathers of the neighbour are issued together (one memory round trip instead of three
+                // dependent ones; the reference tests depth, then normal, then reads the reservoir, R.cu:1924-1934)
                 const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
-                if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906) continue;
+                const f2 nn = fr.normalCur[ni];
                 const DIRes N = fr.di[ni];
+                if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nn)) < 0.906) continue;
                 const float pdf = N.pdf;
                 di_update(S, N.index, (pdf * N.W) * (float)N.M, N.M, pdf, seed);
                 Z += pdf > 0.0f ? N.M : 0u;
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
             S.W = S.pdf > 0.0f ? (1.0f / S.pdf) * (m * S.wSum) : 0.0f;
             R = S;
         }
-        ti = sc.emissive[R.index];
+        const float4* LR = sc.lightRecs + (size_t)R.index * 3;
+        const float4 l0 = LR[0], l1 = LR[1], l2 = LR[2];
+        ti = (uint32_t)__float_as_int(l1.w);
         const TriGeom g = load_tri(sc, ti);
         const f3 ep = tri_random_point(g, seed);
         f3 dir = ep - pos3(pp);
@@ -58,12 +63,11 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
         const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
         const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
-        const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
-        const float triAreaPDF = 1.0f / tri_area(g);
-        const float sa = triAreaPDF * (dist * dist);
+        const float cy = gmax(dot(-dir, mk3(l1.x, l1.y, l1.z)), 0.0f);
+        const float sa = l0.w * (dist * dist);
         const f3 T = ((brdf * cx) * cy) / sa;
-        const Mat lm = load_mat(sc, g.mat);
-        if (length(emission(lm)) > 0.0f) { Lvis = T * emission(lm); Lvis = Lvis * R.W; }       // R.cu:2018-2027
+        const f3 lem = mk3(l2.x, l2.y, l2.z);
+        if (length(lem) > 0.0f) { Lvis = T * lem; Lvis = Lvis * R.W; }                         // R.cu:2018-2027
         Lsky = T * st.sky;                                                                     // R.cu:2028-2031
         ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
         fr.depth[i] = pp.hitDistance;
