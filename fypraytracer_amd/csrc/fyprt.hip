@@ -4,7 +4,6 @@
 // Renderer.cu:37-53, :70, :244-283 — SURVEY.md §8 a14).
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,7 +57,7 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[8] = {2, 1, 6, 0, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[8] = {2, 1, 6, 0, 128, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters;
 
@@ -129,12 +128,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
     HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
     HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n));
-    {   // shadow-task slots: 256 per setup workgroup, grid padded to whole groups of 8 tile rows (tile order 2)
-        const size_t tilesX = (w + 15u) / 16u, tilesY = (h + 15u) / 16u;
-        const size_t maxGroups = std::max(tilesX * ((tilesY + 7u) / 8u) * 8u, ((tilesX * tilesY + 7u) / 8u) * 8u);
-        HIPCHK(c, c->shadowTasks.alloc(maxGroups * 256u * 4u));
-        HIPCHK(c, c->queueCounters.alloc(maxGroups + 4u));
-    }
+    HIPCHK(c, c->shadowTasks.alloc(n * 4));
     // cudaMemset(…, 0, …) of every buffer: Renderer.cu:333-355, :372, :393, :414
     HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->image.p, 0, c->image.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->payload.p, 0, c->payload.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->depth.p, 0, c->depth.bytes(), c->stream));
@@ -347,7 +341,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
-                ShadowQueue q{c->shadowTasks.p, c->queueCounters.p + 4, c->queueCounters.p, grid.x};
+                ShadowQueue q{c->shadowTasks.p, c->queueCounters.p, (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128)};
                 HIPCHK(c, hipMemsetAsync(c->queueCounters.p, 0, 16, c->stream));
                 hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st, q);
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));

@@ -17,9 +17,7 @@
 
 namespace rt {
 
-// Task storage is slotted per setup workgroup (256 slots each, the first counts[wg] are valid), so appending needs no
-// global atomic at all; the only global atomic is the persistent waves' chunk grab on `head` (one per <= 256 rays).
-struct ShadowQueue { float4* tasks; uint32_t* counts; uint32_t* head; uint32_t numChunks; };
+struct ShadowQueue { float4* tasks; uint32_t* counters; uint32_t chunk; };   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
 constexpr int kRefillLanes = 16;
 
 __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
@@ -74,16 +72,20 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         fr.depth[i] = pp.hitDistance;
         fr.diPrev[i] = R;
     }
-    // ---- compaction of the live lanes into the workgroup's slots: ballot + prefix popcount inside a wave, a 4-entry
-    //      LDS prefix across the waves; the workgroup's count goes to counts[blockIdx] (no global atomic: a single
-    //      counter word saturates near 88 atomics/us — one per wave cost 0.4 ms, one per workgroup still 0.1 ms)
+    // ---- compaction of the live lanes into the task queue: ballot + prefix popcount inside a wave, a 4-entry LDS
+    //      prefix across the workgroup's waves, ONE atomic per workgroup (a single counter word saturates near
+    //      88 atomics/us: one per wave = 34 560 per 1080p frame cost 0.4 ms)
     __shared__ uint32_t s_count[kBlock / 64];
+    __shared__ uint32_t s_base;
     const unsigned long long mask = __ballot(live);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0u) s_count[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
-    if (threadIdx.x == 0u) q.counts[blockIdx.x] = s_count[0] + s_count[1] + s_count[2] + s_count[3];
-    const uint32_t s_base = blockIdx.x * (uint32_t)kBlock;
+    if (threadIdx.x == 0u) {
+        const uint32_t n = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+        s_base = n ? atomicAdd(q.counters + 0, n) : 0u;
+    }
+    __syncthreads();
     // optional: order the workgroup's tasks by light (counting sort in LDS) so that neighbouring lanes of the trace
     // kernel aim at the same light — coherent shadow rays share their BVH path near the light
     __shared__ uint32_t s_hist[256];
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     int32_t* lds = s_stack + threadIdx.x;
     int32_t spill[kLdsStack + kSpillStack - kTraceLds];
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = q.counters[0];
     const bool counting = sc.rayCounter != nullptr;
     LaneRay r; r.cur = kExit; r.top = 0;
     bool active = false;                                           // lane owns a ray that is still being traced
@@ -146,7 +149,6 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     f3 pendingRadiance = splat3(0.0f);
     bool more = true;                                              // wave-uniform: tasks may remain (in the queue or in this wave's chunk)
     uint32_t chunkNext = 0, chunkEnd = 0;                          // wave-uniform: this wave's claimed range of the queue
-    bool queueLeft = true;                                         // wave-uniform: unclaimed chunks may remain
     while (true) {
         // ---------------- refill: idle lanes take the next tasks of the wave's chunk; a new chunk is stolen from the queue head when it runs dry
         const unsigned long long idle = __ballot(!active);
@@ -156,18 +158,17 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             if (pending) { epilogue(fr, r.pixel, rgb1(pendingRadiance)); pending = false; }
         }
         if (more && (uint32_t)__popcll(idle) >= (uint32_t)kRefillLanes) {
-            if (chunkNext >= chunkEnd) {             // steal the next setup-workgroup's worth of tasks
-                uint32_t c = 0;
-                if (lane == 0u) c = atomicAdd(q.head, 1u);
-                c = (uint32_t)__shfl((int)c, 0);
-                queueLeft = c + 1u < q.numChunks;
-                if (c < q.numChunks) { chunkNext = c * (uint32_t)kBlock; chunkEnd = chunkNext + q.counts[c]; }
-                else { chunkNext = chunkEnd = 0u; }
+            if (chunkNext >= chunkEnd) {
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(q.counters + 1, q.chunk);
+                base = (uint32_t)__shfl((int)base, 0);
+                chunkNext = base < total ? base : total;
+                chunkEnd = (base + q.chunk < total) ? base + q.chunk : total;
             }
             const uint32_t slot = chunkNext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t want = (uint32_t)__popcll(idle), avail = chunkEnd - chunkNext;
             chunkNext += (want < avail) ? want : avail;
-            more = chunkNext < chunkEnd || queueLeft;
+            more = chunkNext < chunkEnd || chunkEnd < total;
             if (!active && slot < chunkEnd) {
                 const float4* t = q.tasks + (size_t)slot * 4;
                 const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
