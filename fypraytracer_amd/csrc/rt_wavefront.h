@@ -17,7 +17,7 @@
 
 namespace rt {
 
-struct ShadowQueue { float4* tasks; uint32_t* counters; uint32_t chunk; };   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
+struct ShadowQueue { float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes; };   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
 constexpr int kRefillLanes = 16;
 
 __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
@@ -152,12 +152,12 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     while (true) {
         // ---------------- refill: idle lanes take the next tasks of the wave's chunk; a new chunk is stolen from the queue head when it runs dry
         const unsigned long long idle = __ballot(!active);
-        if ((more && (uint32_t)__popcll(idle) >= (uint32_t)kRefillLanes) || __ballot(active) == 0ull) {
+        if ((more && (uint32_t)__popcll(idle) >= q.refillLanes) || __ballot(active) == 0ull) {
             // finished lanes run the fused epilogue together (accumulate, tonemap, pack) — batched here so that it
             // executes once per >= kRefillLanes rays instead of once per finished ray
             if (pending) { epilogue(fr, r.pixel, rgb1(pendingRadiance)); pending = false; }
         }
-        if (more && (uint32_t)__popcll(idle) >= (uint32_t)kRefillLanes) {
+        if (more && (uint32_t)__popcll(idle) >= q.refillLanes) {
             if (chunkNext >= chunkEnd) {
                 uint32_t base = 0;
                 if (lane == 0u) base = atomicAdd(q.counters + 1, q.chunk);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             }
             const unsigned long long act = __ballot(active);
             if (act == 0ull) break;
-            if (more && (64u - (uint32_t)__popcll(act)) >= (uint32_t)kRefillLanes) break;
+            if (more && (64u - (uint32_t)__popcll(act)) >= q.refillLanes) break;
         }
     }
 }
