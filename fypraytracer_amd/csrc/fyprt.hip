@@ -49,6 +49,7 @@ struct fyprt_context {
     // per-pixel buffers
     DevBuf<float4> accum; DevBuf<uint32_t> image; DevBuf<Payload> payload; DevBuf<float> depth; DevBuf<f2> normalA, normalB;
     DevBuf<DIRes> di, diPrev; DevBuf<GIRes> gi, giPrev; bool normalFlip = false;
+    DevBuf<DIRec> drec, dprevA, dprevB; bool dprevFlip = false; int lastTech = -1;
     uint32_t* externalImage = nullptr;
     // scene
     DevBuf<float4> nodes, leafTris, triPos, triShade, mats; DevBuf<DevTexture> texTable; std::vector<DevBuf<uint32_t>> texPixels;
@@ -106,7 +107,7 @@ void fyprt_destroy(fyprt_context* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->accum.release(); c->image.release(); c->payload.release(); c->depth.release(); c->normalA.release(); c->normalB.release();
-    c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release();
+    c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release(); c->drec.release(); c->dprevA.release(); c->dprevB.release();
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
@@ -128,6 +129,9 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
     HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
     HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n));
+    HIPCHK(c, c->drec.alloc(n)); HIPCHK(c, c->dprevA.alloc(n)); HIPCHK(c, c->dprevB.alloc(n));
+    HIPCHK(c, hipMemsetAsync(c->drec.p, 0, c->drec.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->dprevA.p, 0, c->dprevA.bytes(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dprevB.p, 0, c->dprevB.bytes(), c->stream));
     HIPCHK(c, c->shadowTasks.alloc(n * 4));
     // cudaMemset(…, 0, …) of every buffer: Renderer.cu:333-355, :372, :393, :414
     HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->image.p, 0, c->image.bytes(), c->stream));
@@ -136,7 +140,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemsetAsync(c->di.p, 0, c->di.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->diPrev.p, 0, c->diPrev.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->gi.p, 0, c->gi.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->giPrev.p, 0, c->giPrev.bytes(), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->externalImage = nullptr;
+    c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->externalImage = nullptr;
     if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
     return FYPRT_OK;
 }
@@ -306,6 +310,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.accum = c->accum.p; fr.image = c->externalImage ? c->externalImage : c->image.p; fr.payload = c->payload.p; fr.depth = c->depth.p;
     fr.normalPrev = c->normalFlip ? c->normalB.p : c->normalA.p; fr.normalCur = c->normalFlip ? c->normalA.p : c->normalB.p;
     fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p;
+    fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
     if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
@@ -352,13 +357,13 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             }
             else if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
             else hipLaunchKernelGGL(k_gi_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
-            c->normalFlip = !c->normalFlip;
+            if (tech == FYPRT_RESTIR_DI) c->dprevFlip = !c->dprevFlip; else c->normalFlip = !c->normalFlip;
             break;
         }
     }
     HIPCHK(c, hipGetLastError());
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
-    c->lastLaunches = launches;
+    c->lastLaunches = launches; c->lastTech = tech;
     if (s->to_accumulate) c->frameIndex++; else c->frameIndex = 1;       // Renderer.cu:258-261
     return FYPRT_OK;
 }
@@ -421,6 +426,23 @@ int fyprt_read_buffer(fyprt_context* c, int which, void* dst, size_t bytes) {
         case FYPRT_BUF_GI_RESERVOIR: src = c->gi.p; n = c->gi.bytes(); break;
         case FYPRT_BUF_GI_PREV: src = c->giPrev.p; n = c->giPrev.bytes(); break;
         default: return c->fail(FYPRT_EINVAL, "fyprt_read_buffer: unknown buffer");
+    }
+    if (c->lastTech == FYPRT_RESTIR_DI && (which == FYPRT_BUF_NORMAL || which == FYPRT_BUF_DI_RESERVOIR || which == FYPRT_BUF_DI_PREV)) {
+        // ReSTIR DI keeps normal + reservoir packed in 32-byte records (DIRec); unpack into the reference layouts
+        const size_t npx = (size_t)c->W * c->H;
+        std::vector<DIRec> rec(npx);
+        const DIRec* dsrc = (which == FYPRT_BUF_DI_PREV) ? (c->dprevFlip ? c->dprevB.p : c->dprevA.p) : c->drec.p;   // after the flip "read" = just written
+        HIPCHK(c, hipMemcpy(rec.data(), dsrc, npx * sizeof(DIRec), hipMemcpyDeviceToHost));
+        if (which == FYPRT_BUF_NORMAL) {
+            std::vector<float> out(npx * 2);
+            for (size_t p = 0; p < npx; ++p) { out[2 * p] = rec[p].nx; out[2 * p + 1] = rec[p].ny; }
+            std::memcpy(dst, out.data(), std::min(bytes, out.size() * 4));
+        } else {
+            std::vector<DIRes> out(npx);
+            for (size_t p = 0; p < npx; ++p) { out[p].index = rec[p].index; out[p].W = rec[p].W; out[p].pdf = rec[p].pdf; out[p].wSum = rec[p].wSum; out[p].M = rec[p].M; }
+            std::memcpy(dst, out.data(), std::min(bytes, out.size() * sizeof(DIRes)));
+        }
+        return FYPRT_OK;
     }
     if (bytes > n) bytes = n;
     if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));

@@ -37,9 +37,17 @@ struct GISample { float vp[3]; float vn[2]; float sp[3]; float sn[2]; float Lo[3
 struct GIRes { GISample s; float W; uint32_t M; float wSum; };                                                // 72 B
 static_assert(sizeof(Payload) == 40 && sizeof(DIRes) == 20 && sizeof(GIRes) == 72, "layout");
 
+// ReSTIR DI per-pixel record: everything a *neighbour* (spatial reuse) or the *next frame* (temporal reuse) reads
+// about a pixel, packed into one aligned 32-byte line half — primary hit distance, octahedral normal, reservoir —
+// so a gather costs one 32-byte access instead of three scattered ones into the reference's separate 40-byte
+// payload / 8-byte normal / 20-byte reservoir arrays (R.cu:1924-1934, :1764-1765).  Unpacked again by fyprt_read_buffer.
+struct DIRec { float hitDistance, nx, ny; uint32_t index; float W, pdf, wSum; uint32_t M; };
+static_assert(sizeof(DIRec) == 32, "layout");
+
 struct DevFrame {
     float4* accum; uint32_t* image; Payload* payload; float* depth; f2* normalPrev; f2* normalCur;
     DIRes* di; DIRes* diPrev; GIRes* gi; GIRes* giPrev;
+    DIRec* drec; const DIRec* dprevRead; DIRec* dprevWrite;   // DI: this frame's records; previous frame's (read) / next frame's history (write)
     uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder, sortByLight;
 };
 
@@ -48,6 +56,18 @@ struct DevSettings {   // RenderingSettings.h:5-22 with the kernel-side uint8 ca
 };
 
 struct Hit { float t, u, v; int32_t tri; };
+
+RT_DEV DIRec load_rec(const DIRec* p) {
+    const float4* q = reinterpret_cast<const float4*>(p); const float4 a = q[0], b = q[1];
+    DIRec r; r.hitDistance = a.x; r.nx = a.y; r.ny = a.z; r.index = (uint32_t)__float_as_int(a.w);
+    r.W = b.x; r.pdf = b.y; r.wSum = b.z; r.M = (uint32_t)__float_as_int(b.w); return r;
+}
+RT_DEV void store_rec(DIRec* p, float hitDistance, f2 n, const DIRes& r) {
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = make_float4(hitDistance, n.x, n.y, __int_as_float((int)r.index));
+    q[1] = make_float4(r.W, r.pdf, r.wSum, __int_as_float((int)r.M));
+}
+RT_DEV DIRes rec_reservoir(const DIRec& c) { DIRes r; r.index = c.index; r.W = c.W; r.pdf = c.pdf; r.wSum = c.wSum; r.M = c.M; return r; }
 
 RT_DEV f3 pos3(const Payload& p) { return mk3(p.px, p.py, p.pz); }
 RT_DEV f3 nrm3(const Payload& p) { return mk3(p.nx, p.ny, p.nz); }

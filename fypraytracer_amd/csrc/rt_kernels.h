@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
     const f3 pd = ray_direction(cam, x, y);
     const Payload pp = trace_ray(sc, cam.position, pd, stk);
     fr.payload[i] = pp;
-    fr.normalCur[i] = oct_encode(nrm3(pp));
+    const f2 ncur = oct_encode(nrm3(pp));
     DIRes R = di_empty();
     bool finished = false; f3 finalColor = splat3(0.0f);
     Mat hm;
@@ -384,7 +384,10 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
         if (length(emission(hm)) > 0.0f) { finished = true; finalColor = emission(hm); }
     }
     if (finished) {
-        fr.di[i] = R;
+        store_rec(fr.drec + i, pp.hitDistance, ncur, R);
+        // history for the next frame: this frame's normal, the previous reservoir carried over unchanged (the
+        // reference never writes di_prev_reservoirs for pixels finished in Part 1)
+        store_rec(fr.dprevWrite + i, pp.hitDistance, ncur, rec_reservoir(load_rec(fr.dprevRead + i)));
         fr.depth[i] = pp.hitDistance;
         if (inBand) epilogue(fr, i, rgb1(finalColor));
         return;
@@ -399,8 +402,10 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
     R.W = R.pdf > 0.0f ? ((1.0f / R.pdf) * R.wSum) / (float)R.M : 0.0f;
     if (st.useTemporal) {
         const uint32_t prevIdx = prev_pixel(cam, pos3(pp));
-        const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
-        DIRes prev = fr.diPrev[prevIdx];
+        const DIRec prec = load_rec(fr.dprevRead + prevIdx);
+        f2 pn; pn.x = prec.nx; pn.y = prec.ny;
+        const f3 prevN = oct_decode(pn);
+        DIRes prev = rec_reservoir(prec);
         const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99;
         if (valid && prev.M > 0u) {
             const uint32_t lim = st.historyLimit * R.M;
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
             R = Tm;
         }
     }
-    fr.di[i] = R;
+    store_rec(fr.drec + i, pp.hitDistance, ncur, R);
     if (inBand) fr.image[i] = 0u;     // sentinel: ConvertToRGBA(vec4(0)) (Renderer.cu:2746-2750)
 }
 
@@ -427,7 +432,8 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
     const uint32_t i = x + y * fr.W;
     if (fr.image[i] != 0u) return;                                   // Renderer.cu:2787
     uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
-    DIRes R = fr.di[i];
+    const DIRec own = load_rec(fr.drec + i);
+    DIRes R = rec_reservoir(own);
     const Payload pp = fr.payload[i];
     const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
     const f3 pd = ray_direction(cam, x, y);
@@ -436,9 +442,11 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
         { const float pdf = R.pdf; di_update(S, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
         for (uint32_t n = 0; n < st.numNeighbors; ++n) {
             const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
-            const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
-            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906) continue;
-            const DIRes N = fr.di[ni];
+            const DIRec nb = load_rec(fr.drec + ni);
+            const float nd = nb.hitDistance, pdp = pp.hitDistance;
+            f2 nn; nn.x = nb.nx; nn.y = nb.ny;
+            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nn)) < 0.906) continue;
+            const DIRes N = rec_reservoir(nb);
             const float pdf = N.pdf;
             di_update(S, N.index, (pdf * N.W) * (float)N.M, N.M, pdf, seed);
             Z += pdf > 0.0f ? N.M : 0u;
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
         if (length(emission(lm)) > 0.0f) { radiance = T * emission(lm); radiance = radiance * R.W; }
     } else if (hit.hitDistance < 0.0f) radiance = T * st.sky;
     fr.depth[i] = pp.hitDistance;
-    fr.diPrev[i] = R;
+    { f2 on; on.x = own.nx; on.y = own.ny; store_rec(fr.dprevWrite + i, pp.hitDistance, on, R); }
     epilogue(fr, i, rgb1(radiance));
 }
 

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
     f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = 0;
     if (live) {
         uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
-        DIRes R = fr.di[i];
+        const DIRec own = load_rec(fr.drec + i);
+        DIRes R = rec_reservoir(own);
         const Payload pp = fr.payload[i];
         const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
         const f3 pd = ray_direction(cam, x, y);
@@ -37,11 +38,10 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
             { const float pdf = R.pdf; di_update(S, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
             for (uint32_t n = 0; n < st.numNeighbors; ++n) {
                 const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
-                // all three gathers of the neighbour are issued together (one memory round trip instead of three
-                // dependent ones; the reference tests depth, then normal, then reads the reservoir, R.cu:1924-1934)
-                const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
-                const f2 nn = fr.normalCur[ni];
-                const DIRes N = fr.di[ni];
+                const DIRec nb = load_rec(fr.drec + ni);                       // one 32-byte gather per neighbour
+                const float nd = nb.hitDistance, pdp = pp.hitDistance;
+                f2 nn; nn.x = nb.nx; nn.y = nb.ny;
+                const DIRes N = rec_reservoir(nb);
                 if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nn)) < 0.906) continue;
                 const float pdf = N.pdf;
                 di_update(S, N.index, (pdf * N.W) * (float)N.M, N.M, pdf, seed);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         Lsky = T * st.sky;                                                                     // R.cu:2028-2031
         ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
         fr.depth[i] = pp.hitDistance;
-        fr.diPrev[i] = R;
+        { f2 on; on.x = own.nx; on.y = own.ny; store_rec(fr.dprevWrite + i, pp.hitDistance, on, R); }
     }
     // ---- compaction of the live lanes into the task queue: ballot + prefix popcount inside a wave, a 4-entry LDS
     //      prefix across the workgroup's waves, ONE atomic per workgroup (a single counter word saturates near
