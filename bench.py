@@ -30,12 +30,18 @@ KERNEL_NAMES = {7: ["k_di_part1", "k_di_part2_setup", "k_di_part2_trace"], 8: ["
 
 
 def streaming_bytes(tech, pixels_p1, finished_p1, pixels_p2, skipped_p2, neighbors):
-    """Algorithmic per-pixel streaming bytes of this build's own buffers:
-    Part 1: payload 40 w + normal 8 w + reservoir w + temporal (normal 8 + prev reservoir) r + image 4 w,
-            finished (sky/emitter) pixels additionally depth 4 w + accumulation 32 rw;
-    Part 2: image 4 r + reservoir r + payload 40 r + N x (depth 4 + normal 8 + reservoir) r
-            + depth 4 w + prev reservoir w + accumulation 32 rw + image 4 w; skipped pixels image 4 r."""
-    res = 20 if tech == 7 else 72
+    """Algorithmic per-pixel streaming bytes of this build's own buffers.
+    ReSTIR DI (32-byte packed records = hit distance + normal + reservoir):
+      Part 1: payload 40 w + record 32 w + temporal record 32 r + image 4 w; finished (sky/emitter) pixels
+              additionally depth 4 w + history record 32 r + 32 w + accumulation 32 rw;
+      Part 2: image 4 r + record 32 r + payload 40 r + N x record 32 r + depth 4 w + history record 32 w
+              + accumulation 32 rw + image 4 w; skipped pixels image 4 r.
+    ReSTIR GI keeps the reference's separate arrays (72-byte reservoirs)."""
+    if tech == 7:
+        p1 = pixels_p1 * (40 + 32 + 32 + 4) + finished_p1 * (4 + 64 + 32)
+        p2 = pixels_p2 * (4 + 32 + 40 + neighbors * 32 + 4 + 32 + 32 + 4) + skipped_p2 * 4
+        return p1, p2
+    res = 72
     p1 = pixels_p1 * (40 + 8 + res + 8 + res + 4) + finished_p1 * (4 + 32)
     p2 = pixels_p2 * (4 + res + 40 + neighbors * (4 + 8 + res) + 4 + res + 32 + 4) + skipped_p2 * 4
     return p1, p2

@@ -286,3 +286,70 @@ def load_obj(path):
     ln = np.linalg.norm(nrm, axis=1, keepdims=True)
     nrm = nrm / np.where(ln > 0, ln, 1.0)
     return pos.astype(F), nrm.astype(F), uv.astype(F), tris
+
+
+# --------------------------------------------------------------------------- config 2: one ~3k-triangle textured mesh
+def _bent_tube(n_around=30, n_along=53):
+    """Procedural stand-in for Assets/3D Models/Test/banana.obj (1 590 quads -> 3 180 triangles, one BLAS):
+    a tapered tube bent along an arc, 30 x 53 quads = 3 180 triangles, smooth normals, cylindrical uvs."""
+    s = np.linspace(0.0, 1.0, n_along + 1)
+    th = (np.arange(n_around, dtype=np.float64) / n_around) * 2 * np.pi
+    ang = (s - 0.5) * 2.2                                           # bend angle along the arc
+    R = 2.0
+    cx, cy = R * np.sin(ang), R * (1.0 - np.cos(ang))
+    tx, ty = np.cos(ang), np.sin(ang)                               # tangent of the arc (xy plane)
+    nx, ny = -ty, tx                                                # in-plane normal
+    rad = 0.38 * np.sin(np.pi * np.clip(s, 0.02, 0.98)) ** 0.6 + 0.03
+    px = cx[:, None] + rad[:, None] * np.cos(th)[None, :] * nx[:, None]
+    py = cy[:, None] + rad[:, None] * np.cos(th)[None, :] * ny[:, None]
+    pz = rad[:, None] * np.sin(th)[None, :] * np.ones_like(cx)[:, None]
+    pos = np.stack([px, py, pz], -1)
+    nrm = np.stack([np.cos(th)[None, :] * nx[:, None], np.cos(th)[None, :] * ny[:, None], np.sin(th)[None, :] * np.ones_like(cx)[:, None]], -1)
+    uv = np.stack([np.repeat((th / (2 * np.pi))[None, :], n_along + 1, 0), np.repeat(s[:, None], n_around, 1)], -1)
+    i, j = np.meshgrid(np.arange(n_along), np.arange(n_around), indexing="ij")
+    a = i * n_around + j
+    b = i * n_around + (j + 1) % n_around
+    c = (i + 1) * n_around + (j + 1) % n_around
+    d = (i + 1) * n_around + j
+    idx = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)]).astype(np.uint32)
+    return pos.reshape(-1, 3).astype(F), nrm.reshape(-1, 3).astype(F), uv.reshape(-1, 2).astype(F), idx
+
+
+def _stripe_texture(n=256):
+    """ABGR8 (A<<24|B<<16|G<<8|R) procedural albedo map: yellow with brown speckles and green ends."""
+    v, u = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n), indexing="ij")
+    r = 225 - 60 * (np.sin(u * 40) * np.sin(v * 55) > 0.92)
+    g = 200 - 70 * (np.sin(u * 40) * np.sin(v * 55) > 0.92) + 30 * (np.abs(v - 0.5) > 0.44)
+    b = 40 + 20 * (np.abs(v - 0.5) > 0.44)
+    return ((255 << 24) | (b.astype(np.uint32) << 16) | (g.astype(np.uint32) << 8) | r.astype(np.uint32)).astype(np.uint32)
+
+
+def banana_scene(obj_path=None):
+    """BASELINE config 2: one ~3.2k-triangle mesh as a single BLAS, textured diffuse material, transform of
+    WalnutApp.cpp:135-137 (pos (0,-3,0), rot (90,0,0)), a floor quad and one emissive quad above.
+    `obj_path` loads the reference's own banana.obj when available (never on the GPU box); otherwise the
+    procedural stand-in with the same triangle count is used."""
+    sc = Scene()
+    sc.textures = [_stripe_texture()]
+    sc.materials = [
+        Material(albedo=(0.9, 0.8, 0.2), roughness=1.0, metallic=0.0, is_use_albedo_map=True, albedo_map_index=0),   # matBanana, WalnutApp.cpp:76-80
+        Material(albedo=(1, 1, 1), roughness=1.0, metallic=0.0),
+        Material(albedo=(1, 1, 1), emission_color=(1, 1, 1), emission_power=40.0),
+    ]
+    if obj_path is not None:
+        p, n, uv, idx = load_obj(obj_path)
+    else:
+        p, n, uv, idx = _bent_tube()
+    sc.add_new_mesh_to_scene(p, n, uv, idx, pos=(0, -3, 0), rotation=(90, 0, 0), scale_=(1, 1, 1), material_index=0)
+    sc.add_new_mesh_to_scene(*_quad((-8, -4.2, 8), (8, -4.2, 8), (8, -4.2, -8), (-8, -4.2, -8), (0, 1, 0)), material_index=1)
+    sc.add_new_mesh_to_scene(*_quad((-1.5, 1.5, -1.5), (1.5, 1.5, -1.5), (1.5, 1.5, 1.5), (-1.5, 1.5, 1.5), (0, -1, 0)), material_index=2)
+    sc.init_scene_emissive_triangles()
+    return sc
+
+
+def banana_camera(width, height):
+    cam = Camera(45.0, 0.1, 100.0)
+    cam.on_resize(width, height)
+    cam.forward = np.array([-0.6, -0.451, 0.661], dtype=F)          # WalnutApp.cpp:519-520
+    cam.set_position((1.752, -0.845, -2.812))
+    return cam

@@ -29,6 +29,7 @@ def struct_equal(a, b):
 SCENES = {
     "cornell": (lambda: scenes.cornell_box(), scenes.cornell_camera),
     "hall_small": (lambda: scenes.hall_scene_small(), scenes.hall_camera),
+    "banana": (lambda: scenes.banana_scene(), scenes.banana_camera),          # textured single-BLAS mesh (config 2 stand-in)
 }
 
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 TECHS = list(range(9))
 # minimum fraction of pixels whose fp32 accumulated radiance is bit-identical to the reference-order oracle
-REF_MIN_IDENTICAL = {"cornell": 0.975, "hall_small": 0.999}
+REF_MIN_IDENTICAL = {"cornell": 0.975, "hall_small": 0.999, "banana": 0.999}
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +52,7 @@ def _run_pair(scene_name, tech, W, H, frames, product_order, **kw):
     return ctx, orc
 
 
-@pytest.mark.parametrize("scene_name", ["cornell", "hall_small"])
+@pytest.mark.parametrize("scene_name", ["cornell", "hall_small", "banana"])
 @pytest.mark.parametrize("tech", TECHS)
 def test_bit_exact_vs_oracle_product_order(gpu, oracle_built, scene_name, tech):
     W, H = (96, 80) if scene_name == "cornell" else (160, 96)
@@ -79,7 +79,7 @@ def test_bit_exact_vs_oracle_product_order(gpu, oracle_built, scene_name, tech):
     ctx.close()
 
 
-@pytest.mark.parametrize("scene_name", ["cornell", "hall_small"])
+@pytest.mark.parametrize("scene_name", ["cornell", "hall_small", "banana"])
 @pytest.mark.parametrize("tech", TECHS)
 def test_vs_oracle_reference_traversal(gpu, oracle_built, scene_name, tech):
     W, H = (96, 80) if scene_name == "cornell" else (160, 96)
