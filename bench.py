@@ -149,6 +149,8 @@ def main():
     cs = step()
     ctx.set_ray_counting(False)
     p1_rows = (min(H, r1 + halo) - max(0, r0 - halo))
+    if halo > 0 and r0 < halo and min(H, r1 + halo) < H:
+        p1_rows += 1                                   # row H-1: the reference's unsigned neighbour wrap (fyprt.hip)
     halo_rays = (p1_rows - (r1 - r0)) * W if restir else 0
     useful_rays = int(cs.rays) - halo_rays
     if N > 1:

@@ -342,6 +342,14 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             const dim3 g1 = gridFor(p1b, p1e);
             if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             else hipLaunchKernelGGL(k_gi_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
+            // The reference's spatial-neighbour coordinate is computed in unsigned arithmetic (R.cu:1916-1917): an offset
+            // above the first row wraps and clamps to the LAST row.  A band that owns rows < radius therefore also needs
+            // Part 1 of row H-1 (one extra row of recompute) to stay bit-identical to a single-GPU frame.
+            if (c->halo > 0 && c->rowBegin < c->halo && p1e < c->H) {
+                const dim3 g2 = gridFor(c->H - 1u, c->H);
+                if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
+                else hipLaunchKernelGGL(k_gi_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
+            }
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;

@@ -728,13 +728,17 @@ struct Renderer {
             }
         };
         if (tech == RESTIR_DI || tech == RESTIR_GI) {
-            rows(h0, h1, [&](uint32_t x, uint32_t y, Counters& c) {
+            auto part1 = [&](uint32_t x, uint32_t y, Counters& c) {
                 uint32_t i = x + y * W;
                 vec4 col = (tech == RESTIR_DI) ? DI_Part1(x, y, c) : GI_Part1(x, y, c);
                 if (y < y0 || y >= y1) return;                                                                           // halo rows: reservoirs only
                 if (col.x == 0.0f && col.y == 0.0f && col.z == 0.0f && col.w == 0.0f) fr.image[i] = ConvertToRGBA(col);   // sentinel :2746-2750
                 else Epilogue(i, col);
-            });
+            };
+            rows(h0, h1, part1);
+            // tile split only: a neighbour offset above row 0 wraps (unsigned, R.cu:1916-1917) and clamps to the LAST row,
+            // so a band owning rows < radius also needs Part 1 of row H-1
+            if (halo > 0 && y0 < halo && h1 < fr.H) rows(fr.H - 1, fr.H, part1);
             rows(y0, y1, [&](uint32_t x, uint32_t y, Counters& c) {
                 uint32_t i = x + y * W;
                 vec4 u = UnpackABGR(fr.image[i]);
