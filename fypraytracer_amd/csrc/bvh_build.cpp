@@ -1,8 +1,9 @@
 // Host builder of the library's own two-level acceleration structure (layout: rt_host.h).
 // Binned SAH (16 bins, 3 axes) over triangle centroids, up to 4 triangles per leaf, nodes in
-// pre-order so the top of each tree is contiguous in memory; below depth 48 it switches to
-// object-median splits so the traversal stack is bounded (maxDepth is exported and checked
-// against the kernel's stack capacity).  This replaces the reference's recursive builder
+// pre-order so the top of each tree is contiguous in memory.  Depth is bounded BY CONSTRUCTION: every
+// subtree gets a depth budget (kMaxDepth for the TLAS root, the remainder for each BLAS) and a node whose
+// remaining budget is only just enough for a balanced subtree of its size is split at the object median
+// instead of the SAH plane, so leaf depth <= kMaxDepth and the kernels' 32-entry LDS stack never overflows.  This replaces the reference's recursive builder
 // (BVH.cpp:146-309, one triangle per leaf, unordered) — the tree SHAPE is ours; the set of
 // triangles a ray can reach is the same, and the closest hit is found with the reference's
 // own Möller–Trumbore arithmetic, so results match except for exact-tie order.
@@ -24,8 +25,11 @@ struct Box {
 };
 struct Prim { Box b; float c[3]; uint32_t id; };
 
+constexpr uint32_t kMaxDepth = 30;   // leaf depth bound (kernel stack: kStackDepth = 32 >= kMaxDepth + 2)
+inline uint32_t ceilLog2(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) ++l; return l; }
+
 struct Builder {
-    std::vector<Node> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf;
+    std::vector<Node> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepth;
     std::function<int32_t(const Prim*, uint32_t, uint32_t)> makeLeaf;   // (prims, count, depth) -> leaf ref
     static constexpr int kBins = 16;
 
@@ -35,7 +39,10 @@ struct Builder {
         for (uint32_t i = first; i < last; ++i) { nb.grow(p[i].b); cb.grow(p[i].c, p[i].c); }
         outBox = nb;
         int bestAxis = -1, bestBin = -1; float bestCost = FLT_MAX;
-        if (count > 1 && depth < 48) {
+        // leaves needed below this node if split evenly from here on: ceil(count / maxLeaf) -> levels = ceilLog2(that)
+        const uint32_t balancedLevels = ceilLog2((count + maxLeaf - 1) / maxLeaf);
+        const bool mustBalance = depth + balancedLevels + 1 >= depthLimit;
+        if (count > 1 && !mustBalance) {
             for (int axis = 0; axis < 3; ++axis) {
                 const float cmin = cb.lo[axis], cmax = cb.hi[axis];
                 if (!(cmax > cmin)) continue;
@@ -56,6 +63,7 @@ struct Builder {
                 }
             }
         }
+        if (count <= maxLeaf && mustBalance) { maxDepth = std::max(maxDepth, depth); return makeLeaf(p + first, count, depth); }
         if (count <= maxLeaf) {
             const float leafCost = (float)count * nb.area();
             const float splitCost = (bestAxis >= 0) ? 1.0f * nb.area() + bestCost : FLT_MAX;
@@ -95,6 +103,27 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
     out = SceneBVH();
     struct MeshOut { std::vector<Node> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
     std::vector<MeshOut> mo(meshCount);
+    // mesh bounds first: the TLAS only needs them, and its leaf depths set each BLAS's depth budget
+    for (uint32_t m = 0; m < meshCount; ++m) {
+        const fyprt_mesh& me = meshes[m];
+        if (me.triangle_count == 0) continue;
+        for (uint32_t i = 0; i < me.triangle_count; ++i) {
+            const uint32_t* v = triIdx(tris, triStride, me.first_triangle + i);
+            for (int k = 0; k < 3; ++k) mo[m].box.grow(verts[v[k]].position, verts[v[k]].position);
+        }
+        mo[m].valid = true;
+    }
+    std::vector<Prim> mp;
+    for (uint32_t m = 0; m < meshCount; ++m) if (mo[m].valid) {
+        Prim p; p.b = mo[m].box; p.id = m; for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]); mp.push_back(p);
+    }
+    if (mp.empty()) return;
+    std::vector<uint32_t> leafDepth(meshCount, 0);
+    Builder tb; tb.maxLeaf = 1;
+    tb.depthLimit = std::min(kMaxDepth - 2u, ceilLog2((uint32_t)mp.size()) + 6u);   // leave room for the BLASes
+    tb.makeLeaf = [&](const Prim* p, uint32_t, uint32_t depth) -> int32_t { leafDepth[p[0].id] = depth; return INT32_MIN + (int32_t)p[0].id; };   // placeholder
+    Box sceneBox;
+    int32_t troot = tb.build(mp.data(), 0, (uint32_t)mp.size(), 0, sceneBox);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int m = 0; m < (int)meshCount; ++m) {
         const fyprt_mesh& me = meshes[m];
@@ -107,7 +136,7 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
             for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
         }
         MeshOut& o = mo[m];
-        Builder b; b.maxLeaf = 4;
+        Builder b; b.maxLeaf = 4; b.depthLimit = kMaxDepth - leafDepth[m];
         b.makeLeaf = [&](const Prim* p, uint32_t count, uint32_t) -> int32_t {
             const uint32_t first = (uint32_t)o.tris.size();
             for (uint32_t i = 0; i < count; ++i) {
@@ -120,20 +149,10 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
             }
             return ~(int32_t)((first << 2) | (count - 1));
         };
-        o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, o.box);
-        o.nodes.swap(b.nodes); o.depth = b.maxDepth; o.valid = true;
+        Box bb;
+        o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, bb);
+        o.nodes.swap(b.nodes); o.depth = b.maxDepth;
     }
-    // TLAS over the valid meshes; leaves are BLAS roots (relocated below)
-    std::vector<Prim> mp;
-    for (uint32_t m = 0; m < meshCount; ++m) if (mo[m].valid) {
-        Prim p; p.b = mo[m].box; p.id = m; for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]); mp.push_back(p);
-    }
-    if (mp.empty()) return;
-    std::vector<uint32_t> leafDepth(meshCount, 0);
-    Builder tb; tb.maxLeaf = 1;
-    tb.makeLeaf = [&](const Prim* p, uint32_t, uint32_t depth) -> int32_t { leafDepth[p[0].id] = depth; return INT32_MIN + (int32_t)p[0].id; };   // placeholder
-    Box sceneBox;
-    int32_t troot = tb.build(mp.data(), 0, (uint32_t)mp.size(), 0, sceneBox);
     out.tlasNodes = (uint32_t)tb.nodes.size();
     std::vector<uint32_t> nodeOff(meshCount, 0), triOff(meshCount, 0);
     uint32_t no = out.tlasNodes, to = 0;

@@ -58,7 +58,7 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[8] = {2, 1, 6, 0, 64, 24, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[8] = {2, 1, 5, 0, 64, 24, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters;
 
@@ -182,7 +182,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     struct HostOnlyGuard { bool prev; explicit HostOnlyGuard(bool on) : prev(g_hostOnlyAlloc) { g_hostOnlyAlloc = on; } ~HostOnlyGuard() { g_hostOnlyAlloc = prev; } } guard(c->hostOnly);
     // acceleration structure (ours)
     rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
-    if (c->hostBvh.maxDepth + 2 > (uint32_t)(kLdsStack + kSpillStack))
+    if (c->hostBvh.maxDepth + 2 > (uint32_t)kStackDepth)
         return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: BVH depth " + std::to_string(c->hostBvh.maxDepth) + " exceeds the traversal stack");
     HIPCHK(c, c->nodes.alloc(c->hostBvh.nodes.size() * 4)); HIPCHK(c, c->leafTris.alloc(c->hostBvh.tris.size() * 3));
     if (upload(c, c->nodes.p, c->hostBvh.nodes.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
@@ -359,7 +359,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st, q);
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                 if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;
-                const int perCU = c->tuning[2] > 0 ? c->tuning[2] : 6;
+                const int perCU = c->tuning[2] > 0 ? c->tuning[2] : 5;
                 hipLaunchKernelGGL(k_di_part2_trace, dim3((uint32_t)(c->numCUs * perCU)), block, 0, c->stream, c->dsc, fr, q);
                 launches = 3;
             }

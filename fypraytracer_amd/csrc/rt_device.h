@@ -73,21 +73,44 @@ RT_DEV f3 pos3(const Payload& p) { return mk3(p.px, p.py, p.pz); }
 RT_DEV f3 nrm3(const Payload& p) { return mk3(p.nx, p.ny, p.nz); }
 
 // ---------------------------------------------------------------------------------------------
-// Traversal stack: the first kLdsStack entries of every thread live in LDS, laid out
-// [entry][thread] so that a wave's push/pop is one conflict-free ds_write/ds_read_b32; deeper
-// entries (rare: only trees deeper than kLdsStack pending siblings) spill to scratch.
-constexpr int kLdsStack = 24;
-constexpr int kSpillStack = 56;
+// Traversal stack: entirely in LDS, laid out [entry][thread] so that a wave's push/pop is one conflict-free
+// ds_write_b32 / ds_read_b32 (32 KB per 256-thread workgroup, 5 workgroups per CU — the kernels are VGPR-limited to
+// <= 5 waves/SIMD anyway).  kStackDepth bounds the number of pending siblings; the host builder guarantees
+// tree depth + 2 <= kStackDepth (bvh_build.cpp: SAH splits fall back to object-median splits when the remaining depth
+// budget is needed), so there is no spill path — the earlier LDS + scratch hybrid cost a generic flat_load per pop.
+constexpr int kStackDepth = 32;
+constexpr int kLdsStack = kStackDepth;
 constexpr int kBlock = 256;
 constexpr int32_t kExit = (int32_t)0x80000000;
 
 struct Stack {
     int32_t* lds;                 // &shared[threadIdx.x]
-    int32_t spill[kSpillStack];
     int top;
-    RT_DEV void push(int32_t v) { if (top < kLdsStack) lds[top * kBlock] = v; else spill[top - kLdsStack] = v; ++top; }
-    RT_DEV int32_t pop() { --top; return (top < kLdsStack) ? lds[top * kBlock] : spill[top - kLdsStack]; }
+    RT_DEV void push(int32_t v) { lds[top * kBlock] = v; ++top; }
+    RT_DEV int32_t pop() { --top; return lds[top * kBlock]; }
 };
+
+// Both child boxes of a node against one ray.  Same per-component IEEE operations as the scalar form
+// (plane - o) * (1/d) — the reference's slab formula, BVH.cuh:144-146 — but issued as packed fp32
+// (v_pk_add_f32 / v_pk_mul_f32, two planes per instruction): the node quads hold the planes as adjacent pairs
+// (lo.x lo.y | lo.z hi.x | hi.y hi.z), so the ray carries its origin / inverse direction in the matching (x,y), (z,x), (y,z) pairs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct RayPk { v2f oxy, ozx, oyz, ixy, izx, iyz; };
+RT_DEV RayPk make_raypk(f3 o, float ix, float iy, float iz) {
+    RayPk r; r.oxy = v2f{o.x, o.y}; r.ozx = v2f{o.z, o.x}; r.oyz = v2f{o.y, o.z}; r.ixy = v2f{ix, iy}; r.izx = v2f{iz, ix}; r.iyz = v2f{iy, iz}; return r;
+}
+RT_DEV void slab_pair(const float4 q0, const float4 q1, const float4 q2, const RayPk& r, float cut, float& n0, float& f0, float& n1, float& f1) {
+    const v2f a = (v2f{q0.x, q0.y} - r.oxy) * r.ixy;      // lo0.x lo0.y
+    const v2f b = (v2f{q0.z, q0.w} - r.ozx) * r.izx;      // lo0.z hi0.x
+    const v2f c = (v2f{q1.x, q1.y} - r.oyz) * r.iyz;      // hi0.y hi0.z
+    n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.y), __builtin_fminf(a.y, c.x)), __builtin_fmaxf(__builtin_fminf(b.x, c.y), 0.0f));
+    f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.y), __builtin_fmaxf(a.y, c.x)), __builtin_fminf(__builtin_fmaxf(b.x, c.y), cut));
+    const v2f d = (v2f{q1.z, q1.w} - r.oxy) * r.ixy;      // lo1.x lo1.y
+    const v2f e = (v2f{q2.x, q2.y} - r.ozx) * r.izx;      // lo1.z hi1.x
+    const v2f f = (v2f{q2.z, q2.w} - r.oyz) * r.iyz;      // hi1.y hi1.z
+    n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d.x, e.y), __builtin_fminf(d.y, f.x)), __builtin_fmaxf(__builtin_fminf(e.x, f.y), 0.0f));
+    f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d.x, e.y), __builtin_fmaxf(d.y, f.x)), __builtin_fminf(__builtin_fmaxf(e.x, f.y), cut));
+}
 
 RT_DEV float safe_inv(float d) { return 1.0f / ((__builtin_fabsf(d) < 1e-30f) ? __builtin_copysignf(1e-30f, d) : d); }
 
@@ -100,7 +123,7 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     const bool counting = sc.rayCounter != nullptr;        // wave-uniform (kernel argument)
     uint32_t nBox = 0, nTri = 0;
     if (sc.triCount == 0) { if (counting) atomicAdd(sc.rayCounter, 1ull); return h; }
-    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     float closestInfl = h.t * 1.000001f;
     Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
     int32_t cur = sc.rootRef;
@@ -109,17 +132,8 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
             const float4* n = sc.nodes + (size_t)cur * 4;
             const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
             if (counting) nBox += 2;
-            // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-            float ax = (q0.x - o.x) * ix, bx = (q0.w - o.x) * ix;
-            float ay = (q0.y - o.y) * iy, by = (q1.x - o.y) * iy;
-            float az = (q0.z - o.z) * iz, bz = (q1.y - o.z) * iz;
-            const float n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-            const float f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), closestInfl));
-            ax = (q1.z - o.x) * ix; bx = (q2.y - o.x) * ix;
-            ay = (q1.w - o.y) * iy; by = (q2.z - o.y) * iy;
-            az = (q2.x - o.z) * iz; bz = (q2.w - o.z) * iz;
-            const float n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), closestInfl));
+            float n0, f0, n1, f1;
+            slab_pair(q0, q1, q2, pk, closestInfl, n0, f0, n1, f1);
             const bool h0 = n0 <= f0, h1 = n1 <= f1;
             const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             if (h0 && h1) {
@@ -191,7 +205,7 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
         return r;
     }
     uint32_t nBox = 0, nTri = 1;
-    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     const float cut = tL * 1.000001f;
     Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
     int32_t cur = sc.rootRef;
@@ -202,16 +216,8 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
             const float4* n = sc.nodes + (size_t)cur * 4;
             const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
             if (counting) nBox += 2;
-            float ax = (q0.x - o.x) * ix, bx = (q0.w - o.x) * ix;
-            float ay = (q0.y - o.y) * iy, by = (q1.x - o.y) * iy;
-            float az = (q0.z - o.z) * iz, bz = (q1.y - o.z) * iz;
-            const float n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-            const float f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), cut));
-            ax = (q1.z - o.x) * ix; bx = (q2.y - o.x) * ix;
-            ay = (q1.w - o.y) * iy; by = (q2.z - o.y) * iy;
-            az = (q2.x - o.z) * iz; bz = (q2.w - o.z) * iz;
-            const float n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-            const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), cut));
+            float n0, f0, n1, f1;
+            slab_pair(q0, q1, q2, pk, cut, n0, f0, n1, f1);
             const bool h0 = n0 <= f0, h1 = n1 <= f1;
             const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             if (h0 && h1) { const bool swap = n1 < n0; st.push(swap ? c0 : c1); cur = swap ? c1 : c0; }

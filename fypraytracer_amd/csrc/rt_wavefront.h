@@ -125,21 +125,16 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
 
 // per-lane in-flight ray of the persistent trace kernel
 struct LaneRay {
-    f3 o, d; float ix, iy, iz; float tL, cut; uint32_t lightTri, pixel; f3 Lvis, Lsky;
+    f3 o, d; RayPk pk; float tL, cut; uint32_t lightTri, pixel; f3 Lvis, Lsky;
     int32_t cur; int top; int32_t hitTri; bool closestMode; uint32_t nBox, nTri;
 };
 
-template <int LDS_N>
-RT_DEV void lane_push(int32_t* lds, int32_t* spill, int& top, int32_t v) { if (top < LDS_N) lds[top * kBlock] = v; else spill[top - LDS_N] = v; ++top; }
-template <int LDS_N>
-RT_DEV int32_t lane_pop(int32_t* lds, int32_t* spill, int& top) { --top; return (top < LDS_N) ? lds[top * kBlock] : spill[top - LDS_N]; }
-
-constexpr int kTraceLds = 16;
+RT_DEV void lane_push(int32_t* lds, int& top, int32_t v) { lds[top * kBlock] = v; ++top; }
+RT_DEV int32_t lane_pop(int32_t* lds, int& top) { --top; return lds[top * kBlock]; }
 
 __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame fr, ShadowQueue q) {
-    __shared__ int32_t s_stack[kTraceLds * kBlock];
+    __shared__ int32_t s_stack[kStackDepth * kBlock];
     int32_t* lds = s_stack + threadIdx.x;
-    int32_t spill[kLdsStack + kSpillStack - kTraceLds];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = q.counters[0];
     const bool counting = sc.rayCounter != nullptr;
@@ -175,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 r.o = mk3(t0.x, t0.y, t0.z); r.pixel = (uint32_t)__float_as_int(t0.w);
                 r.d = mk3(t1.x, t1.y, t1.z); r.lightTri = (uint32_t)__float_as_int(t1.w);
                 r.Lvis = mk3(t2.x, t2.y, t2.z); r.Lsky = mk3(t3.x, t3.y, t3.z);
-                r.ix = safe_inv(r.d.x); r.iy = safe_inv(r.d.y); r.iz = safe_inv(r.d.z);
+                r.pk = make_raypk(r.o, safe_inv(r.d.x), safe_inv(r.d.y), safe_inv(r.d.z));
                 // light triangle first (same Möller–Trumbore as trace_shadow)
                 float tL = -1.0f;
                 {
@@ -197,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 r.cut = r.tL * 1.000001f;
                 r.hitTri = r.closestMode ? -1 : (int32_t)r.lightTri;
                 r.nBox = 0; r.nTri = 1;
-                r.top = 0; lane_push<kTraceLds>(lds, spill, r.top, kExit);
+                r.top = 0; lane_push(lds, r.top, kExit);
                 r.cur = (sc.triCount == 0) ? kExit : sc.rootRef;
                 active = true;
             }
@@ -210,22 +205,14 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 const float4* n = sc.nodes + (size_t)r.cur * 4;
                 const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                 if (counting) r.nBox += 2;
-                float ax = (q0.x - r.o.x) * r.ix, bx = (q0.w - r.o.x) * r.ix;
-                float ay = (q0.y - r.o.y) * r.iy, by = (q1.x - r.o.y) * r.iy;
-                float az = (q0.z - r.o.z) * r.iz, bz = (q1.y - r.o.z) * r.iz;
-                const float n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-                const float f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), r.cut));
-                ax = (q1.z - r.o.x) * r.ix; bx = (q2.y - r.o.x) * r.ix;
-                ay = (q1.w - r.o.y) * r.iy; by = (q2.z - r.o.y) * r.iy;
-                az = (q2.x - r.o.z) * r.iz; bz = (q2.w - r.o.z) * r.iz;
-                const float n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-                const float f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), r.cut));
+                float n0, f0, n1, f1;
+                slab_pair(q0, q1, q2, r.pk, r.cut, n0, f0, n1, f1);
                 const bool h0 = n0 <= f0, h1 = n1 <= f1;
                 const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                if (h0 && h1) { const bool swap = n1 < n0; lane_push<kTraceLds>(lds, spill, r.top, swap ? c0 : c1); r.cur = swap ? c1 : c0; }
+                if (h0 && h1) { const bool swap = n1 < n0; lane_push(lds, r.top, swap ? c0 : c1); r.cur = swap ? c1 : c0; }
                 else if (h0) r.cur = c0;
                 else if (h1) r.cur = c1;
-                else r.cur = lane_pop<kTraceLds>(lds, spill, r.top);
+                else r.cur = lane_pop(lds, r.top);
             }
             // leaves
             if (active && r.cur != kExit) {
@@ -253,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                         else { occluded = true; break; }
                     }
                 }
-                r.cur = occluded ? kExit : lane_pop<kTraceLds>(lds, spill, r.top);
+                r.cur = occluded ? kExit : lane_pop(lds, r.top);
             }
             // finished lanes: select the pixel's radiance, park it until the next batched epilogue
             if (active && r.cur == kExit) {

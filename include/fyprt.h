@@ -229,7 +229,7 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
 /* Performance knobs that never change results (A/B experiments; defaults are the measured best).
  * key 0: tile order — 0 linear, 1 one contiguous eighth of the tiles per XCD, 2 every 8th tile row per XCD.
  * key 1: ReSTIR DI Part 2 — 0 one thread per pixel, 1 setup kernel + shadow-task queue + persistent trace waves.
- * key 2: persistent workgroups per CU for the trace kernel (default 6).
+ * key 2: persistent workgroups per CU for the trace kernel (default 5 = LDS-resident maximum).
  * key 3: order each setup workgroup's shadow tasks by light (LDS counting sort; default 0 — measured neutral).
  * key 4: tasks a persistent wave claims per queue-head atomic (default 64).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24). */
