@@ -27,6 +27,7 @@ struct DevScene {
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
     const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot;
     unsigned long long* rayCounter;   // nullptr = counting off; else [0] rays [1] box tests [2] triangle tests [3] hits
+    uint32_t nodeQuorum;              // leave the inner-node loop when fewer lanes than this are still in it (0 = never)
 };
 
 struct DevCamera { m4 invProj, invView, prevProjView; f3 position; uint32_t W, H; };
@@ -143,7 +144,11 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
             } else if (h0) cur = c0;
             else if (h1) cur = c1;
             else cur = st.pop();
+            // lanes that reached a leaf wait outside this loop; once only a few lanes are still walking inner nodes,
+            // stop and let everybody test their leaves (keeps SIMD lanes busy; pure scheduling, results unchanged)
+            if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
         }
+        if (cur >= 0) continue;
         if (cur == kExit) break;
         const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
         for (uint32_t k = 0; k < cnt; ++k) {
@@ -224,7 +229,9 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
             else if (h0) cur = c0;
             else if (h1) cur = c1;
             else cur = st.pop();
+            if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
         }
+        if (cur >= 0) continue;
         if (cur == kExit) break;
         const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
         for (uint32_t k = 0; k < cnt; ++k) {

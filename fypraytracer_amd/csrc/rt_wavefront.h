@@ -213,9 +213,10 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 else if (h0) r.cur = c0;
                 else if (h1) r.cur = c1;
                 else r.cur = lane_pop(lds, r.top);
+                if ((uint32_t)__popcll(__ballot(r.cur >= 0)) < sc.nodeQuorum) break;
             }
             // leaves
-            if (active && r.cur != kExit) {
+            if (active && r.cur < 0 && r.cur != kExit) {
                 const uint32_t code = (uint32_t)~r.cur, first = code >> 2, cnt = (code & 3u) + 1u;
                 bool occluded = false;
                 for (uint32_t k = 0; k < cnt; ++k) {
