@@ -58,7 +58,7 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[8] = {2, 1, 5, 0, 64, 24, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[8] = {2, 1, 5, 0, 64, 24, 16, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters;
 
@@ -313,7 +313,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
-    c->dsc.nodeQuorum = (uint32_t)c->tuning[6];
+    c->dsc.nodeQuorum = (uint32_t)c->tuning[6];                 // incoherent rays (bounces, shadow rays)
     if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
@@ -341,6 +341,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             const uint32_t p1b = (c->rowBegin > c->halo) ? c->rowBegin - c->halo : 0u;
             const uint32_t p1e = (c->rowEnd + c->halo < c->H) ? c->rowEnd + c->halo : c->H;
             const dim3 g1 = gridFor(p1b, p1e);
+            c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // Part 1 traces coherent primary rays only
             if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             else hipLaunchKernelGGL(k_gi_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             // The reference's spatial-neighbour coordinate is computed in unsigned arithmetic (R.cu:1916-1917): an offset
@@ -351,6 +352,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
                 else hipLaunchKernelGGL(k_gi_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
             }
+            c->dsc.nodeQuorum = (uint32_t)c->tuning[6];
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--scene", default="hall")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--set", nargs="*", default=[], help="fixed knobs key=value")
     a = ap.parse_args()
     W, H = a.width, a.height
     sc = scenes.hall_scene() if a.scene == "hall" else scenes.hall_scene_small()
@@ -32,6 +33,9 @@ def main():
     ctx.resize(W, H)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
+    for kv in a.set:
+        k, v = kv.split("=")
+        ctx.set_tuning(int(k), int(v))
     st = capi.Settings(technique=a.technique, light_bounces=2 if a.technique != 7 else 1, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
     res = {v: [] for v in a.values}
     allparts = {}
