@@ -58,7 +58,7 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[8] = {2, 1, 5, 0, 64, 24, 16, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[8] = {2, 1, 5, 0, 128, 24, 16, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters;
 
@@ -357,7 +357,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
-                ShadowQueue q{c->shadowTasks.p, c->queueCounters.p, (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 64), (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24)};
+                ShadowQueue q{c->shadowTasks.p, c->queueCounters.p, (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128), (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24)};
                 HIPCHK(c, hipMemsetAsync(c->queueCounters.p, 0, 16, c->stream));
                 hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st, q);
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));

@@ -231,7 +231,7 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 1: ReSTIR DI Part 2 — 0 one thread per pixel, 1 setup kernel + shadow-task queue + persistent trace waves.
  * key 2: persistent workgroups per CU for the trace kernel (default 5 = LDS-resident maximum).
  * key 3: order each setup workgroup's shadow tasks by light (LDS counting sort; default 0 — measured neutral).
- * key 4: tasks a persistent wave claims per queue-head atomic (default 64).
+ * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
  * key 6: inner-node loop quorum for incoherent rays: lanes waiting at a leaf are served once fewer than this many
  *        lanes are still walking inner nodes (default 16; 0 = classic while-while).  key 7: the same for the
