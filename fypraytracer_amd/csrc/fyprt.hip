@@ -313,7 +313,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
-    c->dsc.nodeQuorum = (uint32_t)c->tuning[6];                 // incoherent rays (bounces, shadow rays)
+    c->dsc.nodeQuorum = (uint32_t)c->tuning[7];                 // 0 by default: measured best for every fused per-pixel kernel
     if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
@@ -352,7 +352,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
                 else hipLaunchKernelGGL(k_gi_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
             }
-            c->dsc.nodeQuorum = (uint32_t)c->tuning[6];
+            if (tech == FYPRT_RESTIR_DI) c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;

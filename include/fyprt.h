@@ -233,9 +233,9 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 3: order each setup workgroup's shadow tasks by light (LDS counting sort; default 0 — measured neutral).
  * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
- * key 6: inner-node loop quorum for incoherent rays: lanes waiting at a leaf are served once fewer than this many
- *        lanes are still walking inner nodes (default 16; 0 = classic while-while).  key 7: the same for the
- *        coherent primary-ray kernels (ReSTIR Part 1; default 0). */
+ * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
+ *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).
+ * key 7: the same for every other kernel (default 0: measured neutral or slightly negative there). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 
 /* Library / build identification ("fyprt <version> gfx950 ..."). */
