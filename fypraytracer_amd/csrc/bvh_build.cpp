@@ -23,7 +23,7 @@ struct Box {
     void grow(const Box& b) { grow(b.lo, b.hi); }
     float area() const { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return (dx < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx); }
 };
-struct Prim { Box b; float c[3]; uint32_t id; uint32_t extra = 0; };   // extra: levels already below this primitive (TLAS entries)
+struct Prim { Box b; float c[3]; uint32_t id; };
 
 constexpr uint32_t kMaxDepth = 30;   // leaf depth bound (kernel stack: kStackDepth = 32 >= kMaxDepth + 2)
 inline uint32_t ceilLog2(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) ++l; return l; }
@@ -41,9 +41,7 @@ struct Builder {
         int bestAxis = -1, bestBin = -1; float bestCost = FLT_MAX;
         // leaves needed below this node if split evenly from here on: ceil(count / maxLeaf) -> levels = ceilLog2(that)
         const uint32_t balancedLevels = ceilLog2((count + maxLeaf - 1) / maxLeaf);
-        uint32_t below = 0;
-        if (maxLeaf == 1) for (uint32_t i = first; i < last; ++i) below = std::max(below, p[i].extra);
-        const bool mustBalance = depth + balancedLevels + 1 + below >= depthLimit;
+        const bool mustBalance = depth + balancedLevels + 1 >= depthLimit;
         if (count > 1 && !mustBalance) {
             for (int axis = 0; axis < 3; ++axis) {
                 const float cmin = cb.lo[axis], cmax = cb.hi[axis];
@@ -103,9 +101,29 @@ inline const uint32_t* triIdx(const uint8_t* tris, uint32_t stride, uint32_t i) 
 void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
                    uint32_t meshCount, SceneBVH& out) {
     out = SceneBVH();
-    struct MeshOut { std::vector<Node> nodes; std::vector<Tri> tris; std::vector<uint32_t> height; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
+    struct MeshOut { std::vector<Node> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
     std::vector<MeshOut> mo(meshCount);
-    // ---- one SAH BLAS per mesh (world-space triangles)
+    // mesh bounds first: the TLAS only needs them, and its leaf depths set each BLAS's depth budget
+    for (uint32_t m = 0; m < meshCount; ++m) {
+        const fyprt_mesh& me = meshes[m];
+        if (me.triangle_count == 0) continue;
+        for (uint32_t i = 0; i < me.triangle_count; ++i) {
+            const uint32_t* v = triIdx(tris, triStride, me.first_triangle + i);
+            for (int k = 0; k < 3; ++k) mo[m].box.grow(verts[v[k]].position, verts[v[k]].position);
+        }
+        mo[m].valid = true;
+    }
+    std::vector<Prim> mp;
+    for (uint32_t m = 0; m < meshCount; ++m) if (mo[m].valid) {
+        Prim p; p.b = mo[m].box; p.id = m; for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]); mp.push_back(p);
+    }
+    if (mp.empty()) return;
+    std::vector<uint32_t> leafDepth(meshCount, 0);
+    Builder tb; tb.maxLeaf = 1;
+    tb.depthLimit = std::min(kMaxDepth - 2u, ceilLog2((uint32_t)mp.size()) + 6u);   // leave room for the BLASes
+    tb.makeLeaf = [&](const Prim* p, uint32_t, uint32_t depth) -> int32_t { leafDepth[p[0].id] = depth; return INT32_MIN + (int32_t)p[0].id; };   // placeholder
+    Box sceneBox;
+    int32_t troot = tb.build(mp.data(), 0, (uint32_t)mp.size(), 0, sceneBox);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int m = 0; m < (int)meshCount; ++m) {
         const fyprt_mesh& me = meshes[m];
@@ -118,7 +136,7 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
             for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
         }
         MeshOut& o = mo[m];
-        Builder b; b.maxLeaf = 4; b.depthLimit = 22;                 // leaves <= depth 21 inside the BLAS; the TLAS gets the rest of kMaxDepth
+        Builder b; b.maxLeaf = 4; b.depthLimit = kMaxDepth - leafDepth[m];
         b.makeLeaf = [&](const Prim* p, uint32_t count, uint32_t) -> int32_t {
             const uint32_t first = (uint32_t)o.tris.size();
             for (uint32_t i = 0; i < count; ++i) {
@@ -131,51 +149,11 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
             }
             return ~(int32_t)((first << 2) | (count - 1));
         };
-        o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, o.box);
-        o.nodes.swap(b.nodes); o.depth = b.maxDepth; o.valid = true;
-        // height of every inner node (pre-order storage: children have larger indices)
-        o.height.assign(o.nodes.size(), 0);
-        for (int i = (int)o.nodes.size() - 1; i >= 0; --i) {
-            const Node& n = o.nodes[i];
-            const uint32_t h0 = n.child0 >= 0 ? o.height[n.child0] : 0u, h1 = n.child1 >= 0 ? o.height[n.child1] : 0u;
-            o.height[i] = 1u + std::max(h0, h1);
-        }
+        Box bb;
+        o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, bb);
+        o.nodes.swap(b.nodes); o.depth = b.maxDepth;
     }
-    // ---- TLAS entry points.  The reference's TLAS has one leaf per mesh (Scene::CreateBVHnodesFromSceneMeshes,
-    //      Scene.cpp:111-127); meshes overlap heavily (columns and drapes inside the hall), so a ray would enter many
-    //      BLAS roots.  Here large BLAS nodes are "opened": the entry with the largest surface area is replaced by its
-    //      two children until there are ~16 entries per mesh, and the TLAS is built over those entries (still two
-    //      levels: every BLAS stays intact, the TLAS just points into it below the root where that pays).
-    struct Entry { float area; uint32_t mesh; int32_t ref; Box box; };
-    auto cmp = [](const Entry& a, const Entry& b) { return a.area < b.area; };
-    std::vector<Entry> heap, done;
-    uint32_t validMeshes = 0;
-    for (uint32_t m = 0; m < meshCount; ++m) if (mo[m].valid) { heap.push_back({mo[m].box.area(), m, mo[m].root, mo[m].box}); ++validMeshes; }
-    if (heap.empty()) return;
-    std::make_heap(heap.begin(), heap.end(), cmp);
-    const size_t target = std::min<size_t>(4096, std::max<size_t>(256, (size_t)validMeshes * 16));
-    while (!heap.empty() && heap.size() + done.size() < target) {
-        std::pop_heap(heap.begin(), heap.end(), cmp); Entry e = heap.back(); heap.pop_back();
-        if (e.ref < 0) { done.push_back(e); continue; }             // a leaf cannot be opened
-        const Node& n = mo[e.mesh].nodes[e.ref];
-        Box b0, b1; std::memcpy(b0.lo, n.lo0, 12); std::memcpy(b0.hi, n.hi0, 12); std::memcpy(b1.lo, n.lo1, 12); std::memcpy(b1.hi, n.hi1, 12);
-        heap.push_back({b0.area(), e.mesh, n.child0, b0}); std::push_heap(heap.begin(), heap.end(), cmp);
-        heap.push_back({b1.area(), e.mesh, n.child1, b1}); std::push_heap(heap.begin(), heap.end(), cmp);
-    }
-    done.insert(done.end(), heap.begin(), heap.end());
-    std::vector<Prim> ep(done.size());
-    for (size_t i = 0; i < done.size(); ++i) {
-        Prim& p = ep[i]; p.b = done[i].box; p.id = (uint32_t)i;
-        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
-        p.extra = done[i].ref >= 0 ? mo[done[i].mesh].height[done[i].ref] : 0u;   // levels still below this entry
-    }
-    std::vector<uint32_t> entryDepth(done.size(), 0);
-    Builder tb; tb.maxLeaf = 1; tb.depthLimit = kMaxDepth;
-    tb.makeLeaf = [&](const Prim* p, uint32_t, uint32_t depth) -> int32_t { entryDepth[p[0].id] = depth; return INT32_MIN + (int32_t)p[0].id; };   // placeholder
-    Box sceneBox;
-    int32_t troot = tb.build(ep.data(), 0, (uint32_t)ep.size(), 0, sceneBox);
     out.tlasNodes = (uint32_t)tb.nodes.size();
-    // ---- one node array: TLAS first, then every BLAS; one leaf-triangle array
     std::vector<uint32_t> nodeOff(meshCount, 0), triOff(meshCount, 0);
     uint32_t no = out.tlasNodes, to = 0;
     for (uint32_t m = 0; m < meshCount; ++m) { nodeOff[m] = no; triOff[m] = to; no += (uint32_t)mo[m].nodes.size(); to += (uint32_t)mo[m].tris.size(); }
@@ -186,16 +164,16 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
     };
     auto resolveTlas = [&](int32_t ref) -> int32_t {
         if (ref >= 0) return ref;                                    // TLAS inner node (already global: TLAS is first)
-        const Entry& e = done[(uint32_t)(ref - INT32_MIN)];
-        return relocate(e.ref, e.mesh);
+        uint32_t m = (uint32_t)(ref - INT32_MIN);
+        return relocate(mo[m].root, m);
     };
     out.nodes.reserve(no); out.tris.reserve(to);
     for (Node n : tb.nodes) { n.child0 = resolveTlas(n.child0); n.child1 = resolveTlas(n.child1); out.nodes.push_back(n); }
     for (uint32_t m = 0; m < meshCount; ++m) {
         for (Node n : mo[m].nodes) { n.child0 = relocate(n.child0, m); n.child1 = relocate(n.child1, m); out.nodes.push_back(n); }
         out.tris.insert(out.tris.end(), mo[m].tris.begin(), mo[m].tris.end());
+        if (mo[m].valid) out.maxDepth = std::max(out.maxDepth, leafDepth[m] + mo[m].depth);
     }
-    for (size_t i = 0; i < done.size(); ++i) out.maxDepth = std::max(out.maxDepth, entryDepth[i] + ep[0].extra * 0u + (done[i].ref >= 0 ? mo[done[i].mesh].height[done[i].ref] : 0u));
     out.rootRef = resolveTlas(troot);
 }
 
