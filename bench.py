@@ -110,29 +110,40 @@ def main():
     build_s = time.time() - t0
     ctx.set_camera(cam)
 
-    # the image lives in a torch tensor so the RCCL gather needs no copy
-    image = torch.zeros(H * W, dtype=torch.int32, device="cuda")
-    ctx.set_external_image(image.data_ptr())
-    gathered = None
-    ext_stream = torch.cuda.ExternalStream(ctx.stream()) if N > 1 else None
-
+    # The image lives in torch tensors so the RCCL gather needs no copy.  Two buffers alternate per frame: the gather of
+    # frame k (on RCCL's stream, ordered after frame k's kernels through the context stream) overlaps frame k+1's kernels.
+    images = [torch.zeros(H * W, dtype=torch.int32, device="cuda") for _ in range(2)]
+    ext_stream = torch.cuda.ExternalStream(ctx.stream())
+    pending = [None, None]                          # outstanding gather per image buffer
+    gathered_box = [None]
     frame_no = [0]
-    gathered_box = [gathered]
     part_ms = np.zeros(4)
 
-    def step(collect=False):
+    def step():
+        """One frame, fully asynchronous on the context's stream (hipEvents around every launch are recorded into the
+        library's ring and read back after the timed region)."""
+        k = frame_no[0] & 1
         frame_no[0] += 1
         st.rand_seed = frame_no[0]                    # "randSeed = frame" (SURVEY.md §8d config 4)
-        s = ctx.render(st)                            # blocking; hipEvents around each launch on the context stream
-        if collect:
-            part_ms[:] += np.array(list(s.kernel_ms_part))
+        if pending[k] is not None:                    # the gather that last read this buffer must be done before we overwrite it
+            with torch.cuda.stream(ext_stream):
+                pending[k].wait()
+            pending[k] = None
+        ctx.set_external_image(images[k].data_ptr())
+        ctx.render_async(st)
         if N > 1:
+            image = images[k]
             band = image[r0 * W: r0 * W + rows_per * W] if r1 - r0 == rows_per else torch.nn.functional.pad(image[r0 * W: r1 * W], (0, (rows_per - (r1 - r0)) * W))
-            with torch.cuda.stream(ext_stream):           # ordered after the frame's kernels on the context stream
-                gathered_box[0] = multigpu.gather_image(band, H, W, N, dist)
-        return s
+            with torch.cuda.stream(ext_stream):       # RCCL waits for the frame's kernels, the next frame does not wait for RCCL
+                full = torch.empty(N * rows_per * W, dtype=band.dtype, device=band.device)
+                pending[k] = dist.all_gather_into_tensor(full, band, async_op=True)
+                gathered_box[0] = full
 
     def fence():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if N > 1:
             dist.barrier()
         ctx.synchronize()
@@ -143,9 +154,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(collect=True)
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    n_timed = min(args.steps, 128)
+    for fb in range(n_timed):
+        ms, _n = ctx.frame_timings(fb)
+        part_ms[:] += np.array(ms)
     if N > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,7 +168,9 @@ def main():
 
     # one extra, untimed, instrumented frame: exact ray / box-test / triangle-test counts per launch
     ctx.set_ray_counting(True)
-    cs = step()
+    frame_no[0] += 1
+    st.rand_seed = frame_no[0]
+    cs = ctx.render(st)
     ctx.set_ray_counting(False)
     p1_rows = (min(H, r1 + halo) - max(0, r0 - halo))
     if halo > 0 and r0 < halo and min(H, r1 + halo) < H:
@@ -184,7 +201,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (N = 1 numbers are the ones the judge reads; for N > 1 this is rank 0's band)
         names = KERNEL_NAMES.get(tech, [f"k_technique_{tech}"])
-        avg_ms = part_ms[: len(names)] / args.steps
+        avg_ms = part_ms[: len(names)] / n_timed
         pixels_band = (r1 - r0) * W
         if restir:
             if tech == 7:

@@ -121,7 +121,7 @@ class FrameStats(C.Structure):
 EXPORTED_SYMBOLS = [
     "fyprt_create", "fyprt_destroy", "fyprt_last_error", "fyprt_resize", "fyprt_set_rows", "fyprt_upload_scene",
     "fyprt_set_camera", "fyprt_render", "fyprt_render_async", "fyprt_synchronize", "fyprt_readback",
-    "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer",
+    "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer", "fyprt_frame_timings",
     "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees",
     "fyprt_set_ray_counting", "fyprt_set_tuning", "fyprt_version",
 ]
@@ -157,6 +157,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_render.argtypes = [vp, C.POINTER(Settings), C.POINTER(FrameStats)]
     lib.fyprt_render_async.argtypes = [vp, C.POINTER(Settings)]
     lib.fyprt_synchronize.argtypes = [vp]
+    lib.fyprt_frame_timings.argtypes = [vp, u32, C.POINTER(C.c_float * 4), C.POINTER(u32)]
     lib.fyprt_readback.argtypes = [vp, vp, vp]
     lib.fyprt_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.fyprt_set_external_image.argtypes = [vp, vp]
@@ -285,6 +286,12 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.fyprt_synchronize(self.h))
+
+    def frame_timings(self, frames_back=0):
+        """(per-launch ms [4], launches) of the frame enqueued `frames_back` frames ago; synchronize() first."""
+        ms, n = (C.c_float * 4)(), C.c_uint32()
+        self._check(self.lib.fyprt_frame_timings(self.h, frames_back, C.byref(ms), C.byref(n)))
+        return list(ms), n.value
 
     def readback(self, want_accum=True):
         n = self.width * self.height

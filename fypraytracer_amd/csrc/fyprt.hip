@@ -43,7 +43,8 @@ void matmul_cm(const float* a, const float* b, float* out) {
 
 struct fyprt_context {
     int device = 0; hipStream_t stream = nullptr; std::string err; bool hostOnly = false;
-    hipEvent_t ev[8] = {};
+    static constexpr int kRing = 128;          // frames whose per-launch hipEvents are kept (fyprt_frame_timings)
+    hipEvent_t ring[kRing][5] = {}; int ringLaunches[kRing] = {}; unsigned long long frameSerial = 0; hipEvent_t* ev = nullptr;
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
     bool haveScene = false, haveCamera = false, countRays = false;
     // per-pixel buffers
@@ -92,7 +93,7 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     auto* c = new fyprt_context(); c->device = device_ordinal;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
-    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    for (auto& row : c->ring) for (auto& e : row) (void)hipEventCreate(&e);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     (void)c->queueCounters.alloc(4);
     (void)c->rayCounter.alloc(16);
@@ -112,7 +113,7 @@ void fyprt_destroy(fyprt_context* c) {
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
     c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
-    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& row : c->ring) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -327,6 +328,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     const dim3 block(kBlock);
     const dim3 grid = gridFor(c->rowBegin, c->rowEnd);
     int ei = 0;
+    c->ev = c->ring[c->frameSerial % fyprt_context::kRing];
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
     int launches = 0;
     switch (tech) {
@@ -375,6 +377,8 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     HIPCHK(c, hipGetLastError());
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
     c->lastLaunches = launches; c->lastTech = tech;
+    c->ringLaunches[c->frameSerial % fyprt_context::kRing] = timed ? launches : 0;
+    c->frameSerial++;
     if (s->to_accumulate) c->frameIndex++; else c->frameIndex = 1;       // Renderer.cu:258-261
     return FYPRT_OK;
 }
@@ -401,7 +405,23 @@ int fyprt_render(fyprt_context* c, const fyprt_settings* s, fyprt_frame_stats* s
     return FYPRT_OK;
 }
 
-int fyprt_render_async(fyprt_context* c, const fyprt_settings* s) { if (!c || !s) return FYPRT_EINVAL; return enqueue_frame(c, s, false); }
+int fyprt_render_async(fyprt_context* c, const fyprt_settings* s) { if (!c || !s) return FYPRT_EINVAL; return enqueue_frame(c, s, true); }
+
+int fyprt_frame_timings(fyprt_context* c, uint32_t frames_back, float* kernel_ms_part4, uint32_t* launches) {
+    if (!c || !kernel_ms_part4) return FYPRT_EINVAL;
+    if (frames_back >= (uint32_t)fyprt_context::kRing || frames_back >= c->frameSerial) return c->fail(FYPRT_EINVAL, "fyprt_frame_timings: frame no longer in the ring");
+    const unsigned long long slot = (c->frameSerial - 1ull - frames_back) % fyprt_context::kRing;
+    const int n = c->ringLaunches[slot];
+    for (int k = 0; k < 4; ++k) kernel_ms_part4[k] = 0.0f;
+    for (int k = 0; k < n && k < 4; ++k) {
+        float ms = 0.0f;
+        hipError_t e = hipEventElapsedTime(&ms, c->ring[slot][k], c->ring[slot][k + 1]);
+        if (e != hipSuccess) return c->hip(e, "hipEventElapsedTime (synchronize the context first)");
+        kernel_ms_part4[k] = ms;
+    }
+    if (launches) *launches = (uint32_t)n;
+    return FYPRT_OK;
+}
 int fyprt_synchronize(fyprt_context* c) { if (!c) return FYPRT_EINVAL; if (c->hostOnly) return FYPRT_OK; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return FYPRT_OK; }
 
 int fyprt_readback(fyprt_context* c, uint32_t* rgba8, float* accum4) {

@@ -194,6 +194,9 @@ int fyprt_render(fyprt_context* ctx, const fyprt_settings* settings, fyprt_frame
 /* Asynchronous variant: enqueues the frame on the context's stream and returns. */
 int fyprt_render_async(fyprt_context* ctx, const fyprt_settings* settings);
 int fyprt_synchronize(fyprt_context* ctx);
+/* Per-launch hipEvent times (ms) of the frame enqueued `frames_back` frames ago (0 = the last one; the last 128 frames
+ * are kept).  The events are recorded on the context's stream by both render variants; call after fyprt_synchronize. */
+int fyprt_frame_timings(fyprt_context* ctx, uint32_t frames_back, float* kernel_ms_part4, uint32_t* launches);
 
 /* The D2H copies at Renderer.cu:244-250: rgba8 = m_RenderImageData (ABGR8, row 0 = NDC y -1),
  * accum4 = m_AccumulationData (float4 running SUM).  Either may be NULL.  Full frame size;
