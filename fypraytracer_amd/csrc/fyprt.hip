@@ -61,7 +61,7 @@ struct fyprt_context {
     int lastLaunches = 0;
     int tuning[8] = {2, 1, 5, 0, 128, 24, 16, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
-    DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters;
+    DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
     int fail(int code, const std::string& m) { err = m; return code; }
     int hip(hipError_t e, const char* what) {
@@ -113,6 +113,7 @@ void fyprt_destroy(fyprt_context* c) {
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
     c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
+    c->sortCounts.release(); c->sortOffset.release(); c->sortTotal.release(); c->sortIndex.release(); c->sortKeys.release(); c->sortHist.release();
     for (auto& row : c->ring) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -133,7 +134,13 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, c->drec.alloc(n)); HIPCHK(c, c->dprevA.alloc(n)); HIPCHK(c, c->dprevB.alloc(n));
     HIPCHK(c, hipMemsetAsync(c->drec.p, 0, c->drec.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->dprevA.p, 0, c->dprevA.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->dprevB.p, 0, c->dprevB.bytes(), c->stream));
-    HIPCHK(c, c->shadowTasks.alloc(n * 4));
+    {   // shadow-task storage: 256 slots per setup workgroup (grid padded to whole groups of 8 tile rows), + the sort scratch
+        const size_t tilesX = (w + 15u) / 16u, tilesY = (h + 15u) / 16u;
+        const size_t maxGroups = std::max(tilesX * ((tilesY + 7u) / 8u) * 8u, ((tilesX * tilesY + 7u) / 8u) * 8u);
+        HIPCHK(c, c->shadowTasks.alloc(maxGroups * 256u * 4u));
+        HIPCHK(c, c->sortCounts.alloc(maxGroups)); HIPCHK(c, c->sortKeys.alloc(maxGroups * 256u)); HIPCHK(c, c->sortHist.alloc(maxGroups * kSortBins));
+        HIPCHK(c, c->sortOffset.alloc(maxGroups * kSortBins)); HIPCHK(c, c->sortTotal.alloc(kSortBins)); HIPCHK(c, c->sortIndex.alloc(maxGroups * 256u));
+    }
     // cudaMemset(…, 0, …) of every buffer: Renderer.cu:333-355, :372, :393, :414
     HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->image.p, 0, c->image.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->payload.p, 0, c->payload.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->depth.p, 0, c->depth.bytes(), c->stream));
@@ -359,9 +366,17 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
-                ShadowQueue q{c->shadowTasks.p, c->queueCounters.p, (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128), (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24)};
+                ShadowQueue q{};
+                q.tasks = c->shadowTasks.p; q.counters = c->queueCounters.p;
+                q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24);
+                q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p; q.keys = c->sortKeys.p; q.hist = c->sortHist.p;
+                q.binOffset = c->sortOffset.p; q.binTotal = c->sortTotal.p; q.sorted = c->sortIndex.p;
                 HIPCHK(c, hipMemsetAsync(c->queueCounters.p, 0, 16, c->stream));
                 hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st, q);
+                if (q.sortMode) {
+                    hipLaunchKernelGGL(k_di_sort_scan, dim3(kSortBins), block, 0, c->stream, q);
+                    hipLaunchKernelGGL(k_di_sort_scatter, grid, block, 0, c->stream, q);
+                }
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                 if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;
                 const int perCU = c->tuning[2] > 0 ? c->tuning[2] : 5;

@@ -17,7 +17,13 @@
 
 namespace rt {
 
-struct ShadowQueue { float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes; };   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
+struct ShadowQueue {
+    float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes;
+    // light-sorted mode (tuning key 3): tasks are slotted per setup workgroup, a counting sort over kSortBins light bins
+    // produces `sorted` (task slots in bin order) without a single global atomic
+    uint32_t sortMode, numGroups; uint32_t* counts; uint8_t* keys; uint16_t* hist; uint32_t* binOffset; uint32_t* binTotal; uint32_t* sorted;
+};
+constexpr uint32_t kSortBins = 64;   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
 constexpr int kRefillLanes = 16;
 
 __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
@@ -25,7 +31,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
     const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
     const uint32_t i = x + y * fr.W;
     bool live = inside && fr.image[i] == 0u;                          // Renderer.cu:2787
-    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = 0;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = 0, lightSlot = 0;
     if (live) {
         uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
         const DIRec own = load_rec(fr.drec + i);
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
             S.W = S.pdf > 0.0f ? (1.0f / S.pdf) * (m * S.wSum) : 0.0f;
             R = S;
         }
+        lightSlot = R.index;
         const float4* LR = sc.lightRecs + (size_t)R.index * 3;
         const float4 l0 = LR[0], l1 = LR[1], l2 = LR[2];
         ti = (uint32_t)__float_as_int(l1.w);
@@ -72,54 +79,79 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         fr.depth[i] = pp.hitDistance;
         { f2 on; on.x = own.nx; on.y = own.ny; store_rec(fr.dprevWrite + i, pp.hitDistance, on, R); }
     }
-    // ---- compaction of the live lanes into the task queue: ballot + prefix popcount inside a wave, a 4-entry LDS
-    //      prefix across the workgroup's waves, ONE atomic per workgroup (a single counter word saturates near
-    //      88 atomics/us: one per wave = 34 560 per 1080p frame cost 0.4 ms)
+    // ---- compaction of the live lanes: ballot + prefix popcount inside a wave, a 4-entry LDS prefix across the waves
     __shared__ uint32_t s_count[kBlock / 64];
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_hist[kSortBins];
     const unsigned long long mask = __ballot(live);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0u) s_count[wave] = (uint32_t)__popcll(mask);
+    if (q.sortMode && threadIdx.x < kSortBins) s_hist[threadIdx.x] = 0u;
     __syncthreads();
-    if (threadIdx.x == 0u) {
-        const uint32_t n = s_count[0] + s_count[1] + s_count[2] + s_count[3];
-        s_base = n ? atomicAdd(q.counters + 0, n) : 0u;
-    }
-    __syncthreads();
-    // optional: order the workgroup's tasks by light (counting sort in LDS) so that neighbouring lanes of the trace
-    // kernel aim at the same light — coherent shadow rays share their BVH path near the light
-    __shared__ uint32_t s_hist[256];
-    uint32_t rankInBucket = 0; const uint32_t key = ti & 255u;
-    if (fr.sortByLight) {
-        s_hist[threadIdx.x] = 0u;
+    const uint32_t nLive = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < wave; ++k) rank += s_count[k];
+    uint32_t slot;
+    if (q.sortMode) {
+        // slotted storage (256 slots per workgroup, no global atomic) + this workgroup's row of the light histogram
+        slot = blockIdx.x * (uint32_t)kBlock + rank;
+        const uint32_t key = (uint32_t)(((unsigned long long)lightSlot * kSortBins) / (sc.emissiveCount ? sc.emissiveCount : 1u));
+        if (live) { atomicAdd(&s_hist[key], 1u); q.keys[slot] = (uint8_t)key; }
         __syncthreads();
-        if (live) rankInBucket = atomicAdd(&s_hist[key], 1u);
+        if (threadIdx.x < kSortBins) q.hist[(size_t)blockIdx.x * kSortBins + threadIdx.x] = (uint16_t)s_hist[threadIdx.x];
+        if (threadIdx.x == 0u) q.counts[blockIdx.x] = nLive;
+    } else {
+        // compact queue: ONE atomic per workgroup on the tail (a single counter word saturates near 88 atomics/us:
+        // one per wave = 34 560 per 1080p frame cost 0.4 ms)
+        if (threadIdx.x == 0u) s_base = nLive ? atomicAdd(q.counters + 0, nLive) : 0u;
         __syncthreads();
-        // exclusive prefix over the 256 bins (Hillis–Steele, 8 steps)
-        uint32_t v = s_hist[threadIdx.x];
-        const uint32_t own = v;
-        for (uint32_t d = 1; d < 256u; d <<= 1) {
-            const uint32_t add = (threadIdx.x >= d) ? s_hist[threadIdx.x - d] : 0u;
-            __syncthreads();
-            v += add; s_hist[threadIdx.x] = v;
-            __syncthreads();
-        }
-        s_hist[threadIdx.x] = v - own;
-        __syncthreads();
+        slot = s_base + rank;
     }
     if (live) {
-        uint32_t base = s_base;
-        uint32_t slot;
-        if (fr.sortByLight) slot = base + s_hist[key] + rankInBucket;
-        else {
-            for (uint32_t k = 0; k < wave; ++k) base += s_count[k];
-            slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        }
         float4* t = q.tasks + (size_t)slot * 4;
         t[0] = make_float4(ro.x, ro.y, ro.z, __int_as_float((int)i));
         t[1] = make_float4(rd.x, rd.y, rd.z, __int_as_float((int)ti));
         t[2] = make_float4(Lvis.x, Lvis.y, Lvis.z, 0.0f);
         t[3] = make_float4(Lsky.x, Lsky.y, Lsky.z, 0.0f);
+    }
+}
+
+// Column scan of the histogram matrix hist[group][bin]: binOffset[group][bin] = tasks of `bin` in earlier groups,
+// binTotal[bin] = tasks of `bin` overall.  One workgroup per bin.
+__global__ __launch_bounds__(kBlock) void k_di_sort_scan(ShadowQueue q) {
+    __shared__ uint32_t s_part[kBlock];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (q.numGroups + kBlock - 1u) / kBlock, g0 = t * per, g1 = (g0 + per < q.numGroups) ? g0 + per : q.numGroups;
+    uint32_t sum = 0;
+    for (uint32_t g = g0; g < g1; ++g) sum += q.hist[(size_t)g * kSortBins + bin];
+    s_part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < (uint32_t)kBlock; d <<= 1) {          // Hillis–Steele inclusive scan of the 256 partials
+        const uint32_t add = (t >= d) ? s_part[t - d] : 0u;
+        __syncthreads();
+        s_part[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_part[t] - sum;                                 // exclusive prefix of this thread's range
+    for (uint32_t g = g0; g < g1; ++g) { q.binOffset[(size_t)g * kSortBins + bin] = run; run += q.hist[(size_t)g * kSortBins + bin]; }
+    if (t == (uint32_t)kBlock - 1u) q.binTotal[bin] = s_part[t];
+}
+// Scatter: every task's final position = start of its bin + tasks of that bin in earlier groups + rank inside the group.
+__global__ __launch_bounds__(kBlock) void k_di_sort_scatter(ShadowQueue q) {
+    __shared__ uint32_t s_start[kSortBins];
+    __shared__ uint32_t s_rank[kSortBins];
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    if (t < kSortBins) s_rank[t] = 0u;
+    if (t == 0u) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < kSortBins; ++b) { s_start[b] = run; run += q.binTotal[b]; }
+        if (g == 0u) q.counters[0] = run;                           // total number of tasks (queue tail)
+    }
+    __syncthreads();
+    if (t < q.counts[g]) {
+        const uint32_t slot = g * (uint32_t)kBlock + t, key = q.keys[slot];
+        const uint32_t r = atomicAdd(&s_rank[key], 1u);
+        q.sorted[s_start[key] + q.binOffset[(size_t)g * kSortBins + key] + r] = slot;
     }
 }
 
@@ -165,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             chunkNext += (want < avail) ? want : avail;
             more = chunkNext < chunkEnd || chunkEnd < total;
             if (!active && slot < chunkEnd) {
-                const float4* t = q.tasks + (size_t)slot * 4;
+                const float4* t = q.tasks + (size_t)(q.sortMode ? q.sorted[slot] : slot) * 4;
                 const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
                 r.o = mk3(t0.x, t0.y, t0.z); r.pixel = (uint32_t)__float_as_int(t0.w);
                 r.d = mk3(t1.x, t1.y, t1.z); r.lightTri = (uint32_t)__float_as_int(t1.w);
