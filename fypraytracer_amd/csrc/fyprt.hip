@@ -326,7 +326,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
-    fr.tileOrder = (uint32_t)c->tuning[0]; fr.sortByLight = (uint32_t)c->tuning[3];
+    fr.tileOrder = (uint32_t)c->tuning[0];
     auto gridFor = [&](uint32_t rb, uint32_t re) {
         const uint32_t tilesY = (re - rb + 15u) / 16u;
         if (c->tuning[0] == 2) return dim3(tilesX * ((tilesY + 7u) / 8u) * 8u);

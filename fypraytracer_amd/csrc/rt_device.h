@@ -49,7 +49,7 @@ struct DevFrame {
     float4* accum; uint32_t* image; Payload* payload; float* depth; f2* normalPrev; f2* normalCur;
     DIRes* di; DIRes* diPrev; GIRes* gi; GIRes* giPrev;
     DIRec* drec; const DIRec* dprevRead; DIRec* dprevWrite;   // DI: this frame's records; previous frame's (read) / next frame's history (write)
-    uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder, sortByLight;
+    uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder;
 };
 
 struct DevSettings {   // RenderingSettings.h:5-22 with the kernel-side uint8 casts already applied
@@ -259,6 +259,66 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
         atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, 1ull);
     }
     return r;
+}
+
+// Visibility query of ReSTIR GI Part 2 (R.cu:2356-2366): the reference traces a full closest-hit ray and accepts the
+// neighbour's sample iff |t_closest - dist| <= tol.  Equivalent without finding the closest hit: the interval is cut at
+// dist + tol, any triangle hit closer than dist - tol decides "not visible" at once, and the sample is visible iff some
+// triangle is hit inside [dist - tol, dist + tol].
+RT_DEV bool trace_visible(const DevScene& sc, f3 o, f3 d, float dist, float tol, int32_t* ldsBase) {
+    const bool counting = sc.rayCounter != nullptr;
+    uint32_t nBox = 0, nTri = 0;
+    bool found = false, blocked = false;
+    if (sc.triCount != 0) {
+        const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+        const float tLo = dist - tol, tHi = dist + tol, cut = tHi * 1.000001f;
+        Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
+        int32_t cur = sc.rootRef;
+        while (!blocked) {
+            while (cur >= 0) {
+                const float4* n = sc.nodes + (size_t)cur * 4;
+                const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                if (counting) nBox += 2;
+                float n0, f0, n1, f1;
+                slab_pair(q0, q1, q2, pk, cut, n0, f0, n1, f1);
+                const bool h0 = n0 <= f0, h1 = n1 <= f1;
+                const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                if (h0 && h1) { const bool swap = n1 < n0; st.push(swap ? c0 : c1); cur = swap ? c1 : c0; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else cur = st.pop();
+                if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+            }
+            if (cur >= 0) continue;
+            if (cur == kExit) break;
+            const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (counting) nTri += 1;
+                const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+                const f3 hh = cross(d, e2);
+                const float det = dot(e1, hh), f = 1.0f / det;
+                const f3 s = o - v0;
+                const float u = f * dot(s, hh);
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 q = cross(s, e1);
+                const float v = f * dot(d, q);
+                if (v < 0.0f || (u + v) > 1.0f) continue;
+                const float t = f * dot(e2, q);
+                if (t > 0.0001f) {
+                    if (t < tLo) { blocked = true; break; }
+                    if (t <= tHi) found = true;
+                }
+            }
+            cur = st.pop();
+        }
+    }
+    if (counting) {
+        atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
+        atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, (unsigned long long)((found && !blocked) ? 1 : 0));
+    }
+    return found && !blocked;
 }
 
 // Miss (Renderer.cu:2423-2429; worldPosition / objectIndex zero-filled / -1: DESIGN.md §5 R1)

@@ -609,9 +609,8 @@ __global__ __launch_bounds__(kBlock) void k_gi_part2(DevScene sc, DevCamera cam,
             const float jr = distR > 0.0f ? (distQ * distQ) / (distR * distR) : 0.0f;
             const float jac = jl * jr;
             float pdf = jac > 0.0f ? nlen / jac : 0.0f;
-            const Payload hit = trace_ray(sc, nsp, dR, stk);
             const float tol = gmax(1e-4f, distR * 1e-3f);
-            if (!(__builtin_fabsf(hit.hitDistance - distR) <= tol)) pdf = 0.0f;
+            if (!trace_visible(sc, nsp, dR, distR, tol, stk)) pdf = 0.0f;
             gi_merge(R, N, pdf, seed);
         }
         R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;

@@ -141,6 +141,59 @@ struct ProductTracer : Tracer {
         }
         return r;
     }
+    // Restatement of the product's trace_visible (rt_device.h): interval cut at dist + tol, early "not visible" on any hit
+    // closer than dist - tol, visible iff a hit lies inside [dist - tol, dist + tol].
+    bool TraceVisible(const Ray& ray, float dist, float tol, Counters& c) const override {
+        c.rays++;
+        bool found = false;
+        if (!tris.empty()) {
+            const float ox = ray.origin.x, oy = ray.origin.y, oz = ray.origin.z;
+            const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
+            const float tLo = dist - tol, tHi = dist + tol, cut = tHi * 1.000001f;
+            int32_t stack[128]; int top = 0; int32_t cur = rootRef;
+            auto slab = [&](const float* lo, const float* hi, float& tn) -> bool {
+                float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
+                float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
+                float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
+                float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), cut));
+                tn = tnear; return tnear <= tfar;
+            };
+            while (true) {
+                if (cur >= 0) {
+                    const PNode& n = nodes[cur];
+                    c.boxTests += 2;
+                    float t0, t1; bool h0 = slab(n.lo0, n.hi0, t0), h1 = slab(n.lo1, n.hi1, t1);
+                    if (h0 && h1) { if (t1 < t0) { stack[top++] = n.child0; cur = n.child1; } else { stack[top++] = n.child1; cur = n.child0; } continue; }
+                    else if (h0) { cur = n.child0; continue; }
+                    else if (h1) { cur = n.child1; continue; }
+                } else {
+                    uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const PTri& T = tris[first + k];
+                        c.triTests++;
+                        vec3 v0 = v3(T.v0[0], T.v0[1], T.v0[2]), e1 = v3(T.e1[0], T.e1[1], T.e1[2]), e2 = v3(T.e2[0], T.e2[1], T.e2[2]);
+                        vec3 h = cross(ray.direction, e2);
+                        float a = dot(e1, h), f = 1.0f / a;
+                        vec3 s = ray.origin - v0;
+                        float u = f * dot(s, h);
+                        if (u < 0.0f || u > 1.0f) continue;
+                        vec3 q = cross(s, e1);
+                        float v = f * dot(ray.direction, q);
+                        if (v < 0.0f || (u + v) > 1.0f) continue;
+                        float t = f * dot(e2, q);
+                        if (t > 0.0001f) {
+                            if (t < tLo) return false;
+                            if (t <= tHi) found = true;
+                        }
+                    }
+                }
+                if (top == 0) break;
+                cur = stack[--top];
+            }
+        }
+        if (found) c.hits++;
+        return found;
+    }
 };
-
 }  // namespace orc

@@ -83,6 +83,12 @@ struct Tracer {
     // (R.cu:2016-2031, :1386-1394, :1503-1504).  The reference answers it with a full closest-hit TraceRay — the
     // default here; the product's early-terminating variant is restated in ProductTracer.
     virtual Payload TraceTo(const Ray& ray, uint32_t targetTri, Counters& c) const { (void)targetTri; return Trace(ray, c); }
+    // GI visibility query (R.cu:2356-2366): visible iff |t_closest - dist| <= tol.  The reference finds the closest hit —
+    // the default here; the product's interval-cut / early-out variant is restated in ProductTracer.
+    virtual bool TraceVisible(const Ray& ray, float dist, float tol, Counters& c) const {
+        Payload p = Trace(ray, c);
+        return fabsf(p.hitDistance - dist) <= tol;
+    }
 };
 
 static inline bool IntersectRayAABB(const Ray& ray, const AABB& box) {          // BVH.cuh:124-165
@@ -684,9 +690,8 @@ struct Renderer {
                 float pdf = jac > 0.0f ? nlen / jac : 0.0f;
                 Ray ray{N.sample.samplePoint, normalize(R.sample.visiblePoint - N.sample.samplePoint)};
                 float dist = length(R.sample.visiblePoint - N.sample.samplePoint);
-                Payload hit = tracer.Trace(ray, c);
                 float tol = gmax(1e-4f, dist * 1e-3f);
-                bool visible = fabsf(hit.hitDistance - dist) <= tol;
+                bool visible = tracer.TraceVisible(ray, dist, tol, c);
                 if (!visible) pdf = 0.0f;
                 GI_Merge(R, N, pdf, seed);
             }
