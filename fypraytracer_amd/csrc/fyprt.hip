@@ -54,7 +54,7 @@ struct fyprt_context {
     uint32_t* externalImage = nullptr;
     // scene
     DevBuf<float4> nodes, leafTris, triPos, triShade, mats; DevBuf<DevTexture> texTable; std::vector<DevBuf<uint32_t>> texPixels;
-    DevBuf<uint32_t> emissive; DevBuf<float4> lightRecs; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot;
+    DevBuf<uint32_t> emissive; DevBuf<float4> lightRecs; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot, ltLeafOfTri;
     DevBuf<unsigned long long> rayCounter;
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
@@ -111,7 +111,7 @@ void fyprt_destroy(fyprt_context* c) {
     c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release(); c->drec.release(); c->dprevA.release(); c->dprevB.release();
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
     for (auto& t : c->texPixels) t.release();
-    c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release();
+    c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release(); c->ltLeafOfTri.release();
     c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
     c->sortCounts.release(); c->sortOffset.release(); c->sortTotal.release(); c->sortIndex.release(); c->sortKeys.release(); c->sortHist.release();
     for (auto& row : c->ring) for (auto& e : row) if (e) (void)hipEventDestroy(e);
@@ -266,7 +266,23 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     if (upload(c, c->ltTlas.p, lt.tlas.data(), c->ltTlas.bytes()) || upload(c, c->ltBlas.p, lt.blas.data(), c->ltBlas.bytes()) ||
         upload(c, c->ltFirst.p, lt.first.data(), c->ltFirst.bytes()) || upload(c, c->ltCount.p, lt.count.data(), c->ltCount.bytes()) ||
         upload(c, c->ltRoot.p, lt.root.data(), c->ltRoot.bytes())) return FYPRT_EHIP;
+    // ComputeDirectEmitterPMF (LightTree.cu:170-199) starts with a linear search for the first TLAS leaf whose mesh tree
+    // holds the emitter; the answer does not depend on the shading point, so it is tabled per triangle here (same search
+    // order: first match wins).
+    std::vector<uint32_t> leafOfTri(nT, ~0u);
+    for (uint32_t i = 0; i < (uint32_t)lt.tlas.size(); ++i) {
+        if (!lt.tlas[i].is_leaf) continue;
+        const uint32_t mesh = lt.tlas[i].right_or_emitter;
+        if (mesh >= s->mesh_count) continue;
+        for (uint32_t j = 0; j < lt.count[mesh]; ++j) {
+            const fyprt_lighttree_node& n = lt.blas[lt.first[mesh] + j];
+            if (n.is_leaf && n.right_or_emitter < nT && leafOfTri[n.right_or_emitter] == ~0u) leafOfTri[n.right_or_emitter] = i;
+        }
+    }
+    HIPCHK(c, c->ltLeafOfTri.alloc(nT));
+    if (upload(c, c->ltLeafOfTri.p, leafOfTri.data(), c->ltLeafOfTri.bytes())) return FYPRT_EHIP;
     DevScene& d = c->dsc;
+    d.ltLeafOfTri = c->ltLeafOfTri.p;
     d.nodes = c->nodes.p; d.leafTris = c->leafTris.p; d.rootRef = c->hostBvh.rootRef; d.triCount = nT;
     d.triPos = c->triPos.p; d.triShade = c->triShade.p; d.mats = c->mats.p; d.textures = c->texTable.p; d.textureCount = s->texture_count;
     d.emissive = c->emissive.p; d.emissiveCount = (uint32_t)em.size();

@@ -25,7 +25,7 @@ struct DevScene {
     const DevTexture* textures; uint32_t textureCount;
     const uint32_t* emissive; uint32_t emissiveCount; const float4* lightRecs;
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
-    const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot;
+    const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot; const uint32_t* ltLeafOfTri;
     unsigned long long* rayCounter;   // nullptr = counting off; else [0] rays [1] box tests [2] triangle tests [3] hits
     uint32_t nodeQuorum;              // leave the inner-node loop when fewer lanes than this are still in it (0 = never)
 };

@@ -109,15 +109,19 @@ __global__ __launch_bounds__(kBlock) void k_path(DevScene sc, DevCamera cam, Dev
 
 // ============================================================ light tree (LightTree.cuh:91-117, LightTree.cu, ConeBounds.cuh:47-87)
 RT_DEV float cone_theta_to_box(const DevLTNode& c, f3 p) {
+    // The reference takes max_k acos(clamp(dot_k)) over the 8 box corners (ConeBounds.cuh:47-87).  acos_f is monotone
+    // non-increasing over every float in [-1, 1] (exhaustive check: tests/test_oracle_math.py), so that maximum is
+    // acos_f(min_k clamp(dot_k)) bit for bit: one binary64 acos per cluster instead of eight.  NaN corners are skipped by
+    // fmaxf there and by fminf here; the identity of the maximum (0) is acos_f(1).
     const f3 axis = normalize(mk3(c.centroid[0], c.centroid[1], c.centroid[2]) - p);
-    float maxTheta = 0.0f;
+    float minDot = 1.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const f3 corner = mk3((k & 4) ? c.hi[0] : c.lo[0], (k & 2) ? c.hi[1] : c.lo[1], (k & 1) ? c.hi[2] : c.lo[2]);
         const f3 dir = normalize(corner - p);
-        maxTheta = __builtin_fmaxf(maxTheta, acos_f(gclamp(dot(axis, dir), -1.0f, 1.0f)));
+        minDot = __builtin_fminf(minDot, gclamp(dot(axis, dir), -1.0f, 1.0f));
     }
-    return maxTheta;
+    return acos_f(minDot);
 }
 RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
     const float theta_u = cone_theta_to_box(c, spPos);
@@ -158,14 +162,7 @@ RT_DEV PickedLight pick_light(const DevScene& sc, f3 spPos, uint32_t& seed) {   
 }
 RT_DEV float direct_emitter_pmf(const DevScene& sc, f3 spPos, uint32_t emitterTri) {   // ComputeDirectEmitterPMF, LightTree.cu:156-276
     if (sc.ltTlasCount == 0 || sc.ltTlasRoot == ~0u) return 0.0f;
-    uint32_t tlasLeaf = ~0u;
-    for (uint32_t i = 0; i < sc.ltTlasCount && tlasLeaf == ~0u; ++i) {
-        if (!sc.ltTlas[i].isLeaf) continue;
-        const uint32_t mesh = sc.ltTlas[i].rightOrEmitter;
-        const DevLTNode* b = sc.ltBlas + sc.ltFirst[mesh];
-        for (uint32_t j = 0; j < sc.ltCount[mesh]; ++j)
-            if (b[j].isLeaf && b[j].rightOrEmitter == emitterTri) { tlasLeaf = i; break; }
-    }
+    const uint32_t tlasLeaf = emitterTri < sc.triCount ? sc.ltLeafOfTri[emitterTri] : ~0u;   // the reference's linear search (:170-199), tabled at upload
     if (tlasLeaf == ~0u) return 0.0f;
     float pmf = 1.0f; uint32_t idx = sc.ltTlasRoot;
     const DevLTNode* nodes = sc.ltTlas; uint32_t target = tlasLeaf;

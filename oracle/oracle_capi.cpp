@@ -8,6 +8,7 @@
 
 using namespace orc;
 
+#include <cstring>
 extern "C" {
 
 struct orc_vertex { float position[3], normal[3], uv[2]; };
@@ -171,6 +172,30 @@ float orc_random_float(uint32_t* seed) { return randomFloat(*seed); }
 float orc_sin(float x) { return t_sin(x); }
 float orc_cos(float x) { return t_cos(x); }
 float orc_acos(float x) { return t_acos(x); }
+// Exhaustive check that t_acos is monotone non-increasing over every float in [-1, 1] (2^31 + 1 values): the product
+// evaluates max_k acos(x_k) of ConeThetaToBox (ConeBounds.cuh:47-87) as acos(min_k x_k), which is the same number iff
+// this returns 0.  Returns the number of adjacent pairs (a < b) with t_acos(a) < t_acos(b).
+uint64_t orc_acos_monotone_violations() {
+    // order-preserving map: key k in [0, 2^31] -> float; k < 2^30+... handled through the sign-magnitude bit pattern
+    const uint32_t one = 0x3F800000u;                       // bits of 1.0f; floats in [-1, 0) are keys one-1 .. 0 reversed
+    const int64_t n = (int64_t)one * 2 + 1;                 // -1 .. -0 (one+1 values) then +0 .. 1 (one+1 values), minus the shared step
+    auto at = [&](int64_t k) -> float {                     // k = 0 -> -1.0f, k = one -> -0.0f, k = one+1 -> +0.0f, k = 2*one+1 -> 1.0f
+        uint32_t bits = (k <= (int64_t)one) ? (0x80000000u | (uint32_t)((int64_t)one - k)) : (uint32_t)(k - (int64_t)one - 1);
+        float f; memcpy(&f, &bits, 4); return f;
+    };
+    uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t c = 0; c < 4096; ++c) {
+        const int64_t lo = (n + 1) * c / 4096, hi = (n + 1) * (c + 1) / 4096;   // pairs (k, k+1), k in [lo, hi)
+        float prev = t_acos(at(lo));
+        for (int64_t k = lo; k < hi && k < n; ++k) {
+            const float cur = t_acos(at(k + 1));
+            if (prev < cur || cur != cur) ++bad;
+            prev = cur;
+        }
+    }
+    return bad;
+}
 float orc_pow5(float x) { return t_pow5(x); }
 float orc_uniform_pdf() { return UniformHemispherePDF(); }
 void orc_encode_oct(const float* n3, float* e2) { vec2 e = EncodeOctahedral(v3(n3[0], n3[1], n3[2])); e2[0] = e.x; e2[1] = e.y; }

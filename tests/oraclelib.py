@@ -58,6 +58,7 @@ def _load(name):
         getattr(lib, f).argtypes = [C.c_float]
         getattr(lib, f).restype = C.c_float
     lib.orc_uniform_pdf.restype = C.c_float
+    lib.orc_acos_monotone_violations.restype = C.c_uint64
     lib.orc_encode_oct.argtypes = [vp, vp]
     lib.orc_decode_oct.argtypes = [vp, vp]
     lib.orc_convert_rgba.argtypes = [vp]

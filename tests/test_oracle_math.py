@@ -39,6 +39,13 @@ def test_acos(oracle_built):
     assert L.orc_acos(1.0) == 0.0
 
 
+def test_acos_monotone_exhaustive(oracle_built):
+    """Every adjacent float pair in [-1, 1] (2^31 of them): acos never increases.  This is what lets the product take
+    max_k acos(x_k) of ConeThetaToBox as acos(min_k x_k) and still match the oracle (which keeps the max) bit for bit."""
+    assert lib().orc_acos_monotone_violations() == 0
+    assert lib(libm=True).orc_acos_monotone_violations() == 0
+
+
 def test_pow5(oracle_built):
     L = lib()
     xs = np.linspace(0, 1, 30001).astype(np.float32)
