@@ -3,4 +3,5 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 g++ -O2 -std=c++17 -Wall harness.cpp -o harness -L../csrc -lfyprt -Wl,-rpath,'$ORIGIN/../csrc'
-echo "built $(pwd)/harness"
+g++ -O2 -std=c++17 -Wall -I../../include misutils_check.cpp -o misutils_check
+echo "built $(pwd)/harness $(pwd)/misutils_check"

@@ -3,28 +3,20 @@
 // MainLayer::OnUpdate does, WalnutApp.cpp:532; prev matrices committed as :908-909), print the
 // reference's on-screen statistics (frame time, accumulated frames) and write the frame as a
 // bottom-up 24-bit BMP (MisUtils::SaveABGRToBMP, MisUtils.cpp:13-95).
-//   usage: harness [technique 0-8] [frames] [width] [height] [out.bmp]
+// With a reference image it also prints the benchmark record name MainLayer::SaveBenchmarkResults builds
+// (WalnutApp.cpp:833-875: frame times, technique, its parameters, MSE, PSNR).
+//   usage: harness [technique 0-8] [frames] [width] [height] [out.bmp] [reference.bmp]
 #include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include "HostTypes.h"
+#include "MisUtils.h"
 #include "Renderer.h"
 using namespace fyprt_host;
 
 static void quad(Scene& s, vec3 a, vec3 b, vec3 c, vec3 d, vec3 n, int mat) {
     std::vector<Vertex> v = {{a, n, {0, 0}}, {b, n, {1, 0}}, {c, n, {1, 1}}, {d, n, {0, 1}}};
     s.AddNewMeshToScene(v, {0, 1, 2, 0, 2, 3}, mat);
-}
-static void saveBmp(const char* path, const uint32_t* abgr, uint32_t w, uint32_t h) {
-    const uint32_t row = (w * 3 + 3) & ~3u, size = 54 + row * h;
-    std::vector<uint8_t> f(size, 0);
-    f[0] = 'B'; f[1] = 'M'; std::memcpy(&f[2], &size, 4); uint32_t off = 54, hs = 40; std::memcpy(&f[10], &off, 4); std::memcpy(&f[14], &hs, 4);
-    std::memcpy(&f[18], &w, 4); std::memcpy(&f[22], &h, 4); uint16_t planes = 1, bpp = 24; std::memcpy(&f[26], &planes, 2); std::memcpy(&f[28], &bpp, 2);
-    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) {      // row 0 of the render = bottom of the picture = first BMP row
-        const uint32_t p = abgr[y * w + x]; uint8_t* q = &f[54 + y * row + x * 3];
-        q[0] = (p >> 16) & 0xFF; q[1] = (p >> 8) & 0xFF; q[2] = p & 0xFF;
-    }
-    std::ofstream(path, std::ios::binary).write((const char*)f.data(), f.size());
 }
 int main(int argc, char** argv) {
     const int tech = argc > 1 ? std::atoi(argv[1]) : RESTIR_DI, frames = argc > 2 ? std::atoi(argv[2]) : 16;
@@ -56,6 +48,14 @@ int main(int argc, char** argv) {
     }
     std::printf("Resolution : %ux%u\nTriangles : %zu\nAvg frame time : %.3fms (kernels %.3fms)\nAccumulated frames : %u\n",
                 W, H, scene.triangles.size(), total / frames, renderer.GetLastFrameStats().kernel_ms, renderer.GetCurrentFrameIndex() - 1);
-    if (argc > 5) saveBmp(argv[5], renderer.GetRenderImageDataPtr(), W, H);
+    if (argc > 5 && !MisUtils::SaveABGRToBMP(argv[5], renderer.GetRenderImageDataPtr(), (int)W, (int)H)) { std::fprintf(stderr, "cannot write %s\n", argv[5]); return 1; }
+    if (argc > 6) {
+        std::vector<uint32_t> ref; uint32_t rw = 0, rh = 0;
+        if (!MisUtils::LoadBMPToABGR(argv[6], ref, rw, rh) || rw != W || rh != H) { std::fprintf(stderr, "cannot use reference image %s\n", argv[6]); return 1; }
+        const double mse = MisUtils::ComputeMSE(ref.data(), renderer.GetRenderImageDataPtr(), W, H);
+        std::printf("Record : %s\n", MisUtils::BenchmarkRecordName(s, (float)(total / frames), (float)total, true, mse, MisUtils::ComputePSNR(mse)).c_str());
+    } else {
+        std::printf("Record : %s\n", MisUtils::BenchmarkRecordName(s, (float)(total / frames), (float)total).c_str());
+    }
     return 0;
 }
