@@ -8,6 +8,6 @@ CXXFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -fopenmp -Wall"
 g++ $CXXFLAGS -c bvh_build.cpp -o bvh_build.o
 g++ $CXXFLAGS -c lighttree_build.cpp -o lighttree_build.o
 $HIPCC -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-    ${FYPRT_EXTRA_HIPCC_FLAGS:-} -c fyprt.hip -o fyprt.o
-$HIPCC -shared -fPIC --offload-arch=gfx950 fyprt.o bvh_build.o lighttree_build.o -lgomp -o libfyprt.so
-echo "built $(pwd)/libfyprt.so"
+    ${FYPRT_EXTRA_HIPCC_FLAGS:-} -c fyprt.hip -o ${FYPRT_OBJ:-fyprt.o}
+$HIPCC -shared -fPIC --offload-arch=gfx950 ${FYPRT_OBJ:-fyprt.o} bvh_build.o lighttree_build.o -lgomp -o ${FYPRT_OUT:-libfyprt.so}
+echo "built $(pwd)/${FYPRT_OUT:-libfyprt.so}"

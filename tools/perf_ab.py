@@ -24,8 +24,11 @@ def main():
     ap.add_argument("--scene", default="hall")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--lib", default=None, help="alternative libfyprt build to load")
     ap.add_argument("--set", nargs="*", default=[], help="fixed knobs key=value")
     a = ap.parse_args()
+    if a.lib:
+        capi._lib = capi.load_library(a.lib)
     W, H = a.width, a.height
     sc = scenes.hall_scene() if a.scene == "hall" else scenes.hall_scene_small()
     cam = scenes.hall_camera(W, H)
