@@ -1,6 +1,7 @@
-// Host builder of the library's own two-level acceleration structure (layout: rt_host.h).
-// Binned SAH (16 bins, 3 axes) over triangle centroids, up to 4 triangles per leaf, nodes in
-// pre-order so the top of each tree is contiguous in memory.  Depth is bounded BY CONSTRUCTION: every
+// Host builder of the library's own acceleration structure (layout: rt_host.h).
+// Binned SAH (16 bins, 3 axes) over triangle centroids, up to 4 triangles per leaf, two levels (a tree per mesh under a
+// tree over the meshes) merged into one binary tree, which is then collapsed into 4-wide nodes with 8-bit quantised child
+// boxes (one 64-byte fetch per four children), nodes in pre-order so the top of the tree is contiguous in memory.  Depth is bounded BY CONSTRUCTION: every
 // subtree gets a depth budget (kMaxDepth for the TLAS root, the remainder for each BLAS) and a node whose
 // remaining budget is only just enough for a balanced subtree of its size is split at the object median
 // instead of the SAH plane, so leaf depth <= kMaxDepth and the kernels' 32-entry LDS stack never overflows.  This replaces the reference's recursive builder
@@ -28,8 +29,11 @@ struct Prim { Box b; float c[3]; uint32_t id; };
 constexpr uint32_t kMaxDepth = 30;   // leaf depth bound (kernel stack: kStackDepth = 32 >= kMaxDepth + 2)
 inline uint32_t ceilLog2(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) ++l; return l; }
 
+// binary node of the intermediate SAH tree (both child boxes in the parent)
+struct Node2 { float lo0[3], hi0[3], lo1[3], hi1[3]; int32_t child0, child1; };
+
 struct Builder {
-    std::vector<Node> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepth;
+    std::vector<Node2> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepth;
     std::function<int32_t(const Prim*, uint32_t, uint32_t)> makeLeaf;   // (prims, count, depth) -> leaf ref
     static constexpr int kBins = 16;
 
@@ -87,9 +91,89 @@ struct Builder {
         Box b0, b1;
         int32_t c0 = build(p, first, mid, depth + 1, b0);
         int32_t c1 = build(p, mid, last, depth + 1, b1);
-        Node& n = nodes[self];
+        Node2& n = nodes[self];
         std::memcpy(n.lo0, b0.lo, 12); std::memcpy(n.hi0, b0.hi, 12); std::memcpy(n.lo1, b1.lo, 12); std::memcpy(n.hi1, b1.hi, 12);
-        n.child0 = c0; n.child1 = c1; n.pad[0] = n.pad[1] = 0;
+        n.child0 = c0; n.child1 = c1;
+        return self;
+    }
+};
+
+
+// ---- collapse of the binary tree into 4-wide nodes ------------------------------------------------------------
+// Greedy: starting from a binary node's two children, the child with the largest surface area is replaced by its own
+// two children until there are four (or only leaves are left).  Stack safety is kept BY CONSTRUCTION: an ordered traversal
+// of a k-wide node leaves up to k-1 siblings pending, so a node with stack budget b may only become k wide if every child
+// still fits its binary subtree into b - (k-1) (binary height is the fallback that always fits: one pending entry per level).
+struct Collapser {
+    const std::vector<Node2>& bn; std::vector<uint8_t> height; std::vector<Node> out; uint32_t stackNeed = 0;
+    explicit Collapser(const std::vector<Node2>& b) : bn(b), height(b.size(), 0) {}
+    uint32_t h(int32_t ref) const { return ref < 0 ? 0u : height[(size_t)ref]; }
+    uint32_t computeHeights(int32_t ref) {
+        if (ref < 0) return 0;
+        const uint32_t v = 1u + std::max(computeHeights(bn[ref].child0), computeHeights(bn[ref].child1));
+        height[(size_t)ref] = (uint8_t)v; return v;
+    }
+    struct Child { int32_t ref; Box b; };
+    static void quantise(Node& n, const Child* ch, int k) {
+        Box nb; for (int i = 0; i < k; ++i) nb.grow(ch[i].b);
+        std::memset(&n, 0, sizeof n);
+        n.count = (uint8_t)k;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = nb.lo[a]; n.origin[a] = lo;
+            const double ext = (double)nb.hi[a] - (double)lo;
+            int e = 1;
+            if (ext > 0.0) { int ee; const double m = std::frexp(ext / 254.0, &ee); if (m == 0.5) --ee; e = std::min(254, std::max(1, ee + 127)); }   // 2^(e-127) >= ext/254
+            for (;; ++e) {
+                const double s = std::ldexp(1.0, e - 127); const float sf = (float)s;
+                bool ok = ext <= 254.0 * s;
+                for (int i = 0; i < k && ok; ++i) {
+                    int ql = (int)std::floor(((double)ch[i].b.lo[a] - (double)lo) / s - 0.0625), qh = (int)std::ceil(((double)ch[i].b.hi[a] - (double)lo) / s + 0.0625);
+                    ql = std::min(255, std::max(0, ql)); qh = std::min(255, std::max(0, qh));
+                    while (ql > 0 && !(std::fmaf((float)ql, sf, lo) <= ch[i].b.lo[a])) --ql;
+                    while (qh < 255 && !(std::fmaf((float)qh, sf, lo) >= ch[i].b.hi[a])) ++qh;
+                    ok = std::fmaf((float)ql, sf, lo) <= ch[i].b.lo[a] && std::fmaf((float)qh, sf, lo) >= ch[i].b.hi[a];
+                    n.qlo[a][i] = (uint8_t)ql; n.qhi[a][i] = (uint8_t)qh;
+                }
+                if (ok || e >= 254) break;
+            }
+            n.ex[a] = (uint8_t)e;
+        }
+    }
+    // returns the wide index; `need` = worst-case pending entries below (and including) this node
+    int32_t emit(int32_t ref, uint32_t budget, uint32_t& need) {
+        Child ch[4]; int k = 2;
+        { const Node2& b = bn[ref]; ch[0].ref = b.child0; std::memcpy(ch[0].b.lo, b.lo0, 12); std::memcpy(ch[0].b.hi, b.hi0, 12);
+          ch[1].ref = b.child1; std::memcpy(ch[1].b.lo, b.lo1, 12); std::memcpy(ch[1].b.hi, b.hi1, 12); }
+        while (k < 4) {
+            int best = -1; float bestArea = -1.0f;
+            for (int i = 0; i < k; ++i) {
+                if (ch[i].ref < 0) continue;
+                bool fits = true;                                            // k + 1 children -> child budget = budget - k
+                for (int j = 0; j < k && fits; ++j) if (j != i && h(ch[j].ref) + (uint32_t)k > budget) fits = false;
+                const Node2& c = bn[ch[i].ref];
+                if (h(c.child0) + (uint32_t)k > budget || h(c.child1) + (uint32_t)k > budget) fits = false;
+                if (!fits) continue;
+                const float ar = ch[i].b.area();
+                if (ar > bestArea) { bestArea = ar; best = i; }
+            }
+            if (best < 0) break;
+            const Node2& c = bn[ch[best].ref];
+            for (int j = k; j > best + 1; --j) ch[j] = ch[j - 1];              // the two grandchildren take the child's place
+            ch[best].ref = c.child0; std::memcpy(ch[best].b.lo, c.lo0, 12); std::memcpy(ch[best].b.hi, c.hi0, 12);
+            ch[best + 1].ref = c.child1; std::memcpy(ch[best + 1].b.lo, c.lo1, 12); std::memcpy(ch[best + 1].b.hi, c.hi1, 12);
+            ++k;
+        }
+        const int32_t self = (int32_t)out.size();
+        out.emplace_back();
+        Node n; quantise(n, ch, k);
+        uint32_t below = 0;
+        for (int i = 0; i < k; ++i) {
+            if (ch[i].ref >= 0) { uint32_t cn = 0; n.child[i] = emit(ch[i].ref, budget - (uint32_t)(k - 1), cn); below = std::max(below, cn); }
+            else n.child[i] = ch[i].ref;
+        }
+        for (int i = k; i < 4; ++i) n.child[i] = INT32_MIN;                       // never read: count masks the slot
+        out[(size_t)self] = n;
+        need = (uint32_t)(k - 1) + below;
         return self;
     }
 };
@@ -101,7 +185,7 @@ inline const uint32_t* triIdx(const uint8_t* tris, uint32_t stride, uint32_t i) 
 void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
                    uint32_t meshCount, SceneBVH& out) {
     out = SceneBVH();
-    struct MeshOut { std::vector<Node> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
+    struct MeshOut { std::vector<Node2> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
     std::vector<MeshOut> mo(meshCount);
     // mesh bounds first: the TLAS only needs them, and its leaf depths set each BLAS's depth budget
     for (uint32_t m = 0; m < meshCount; ++m) {
@@ -153,9 +237,10 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
         o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, bb);
         o.nodes.swap(b.nodes); o.depth = b.maxDepth;
     }
-    out.tlasNodes = (uint32_t)tb.nodes.size();
+    // merge into one binary tree (TLAS nodes first, then each BLAS), relocating child references
+    const uint32_t tlasNodes = (uint32_t)tb.nodes.size();
     std::vector<uint32_t> nodeOff(meshCount, 0), triOff(meshCount, 0);
-    uint32_t no = out.tlasNodes, to = 0;
+    uint32_t no = tlasNodes, to = 0;
     for (uint32_t m = 0; m < meshCount; ++m) { nodeOff[m] = no; triOff[m] = to; no += (uint32_t)mo[m].nodes.size(); to += (uint32_t)mo[m].tris.size(); }
     auto relocate = [&](int32_t ref, uint32_t m) -> int32_t {
         if (ref >= 0) return ref + (int32_t)nodeOff[m];
@@ -167,14 +252,23 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
         uint32_t m = (uint32_t)(ref - INT32_MIN);
         return relocate(mo[m].root, m);
     };
-    out.nodes.reserve(no); out.tris.reserve(to);
-    for (Node n : tb.nodes) { n.child0 = resolveTlas(n.child0); n.child1 = resolveTlas(n.child1); out.nodes.push_back(n); }
+    std::vector<Node2> bin; bin.reserve(no); out.tris.reserve(to);
+    for (Node2 n : tb.nodes) { n.child0 = resolveTlas(n.child0); n.child1 = resolveTlas(n.child1); bin.push_back(n); }
     for (uint32_t m = 0; m < meshCount; ++m) {
-        for (Node n : mo[m].nodes) { n.child0 = relocate(n.child0, m); n.child1 = relocate(n.child1, m); out.nodes.push_back(n); }
+        for (Node2 n : mo[m].nodes) { n.child0 = relocate(n.child0, m); n.child1 = relocate(n.child1, m); bin.push_back(n); }
         out.tris.insert(out.tris.end(), mo[m].tris.begin(), mo[m].tris.end());
         if (mo[m].valid) out.maxDepth = std::max(out.maxDepth, leafDepth[m] + mo[m].depth);
     }
-    out.rootRef = resolveTlas(troot);
+    const int32_t binRoot = resolveTlas(troot);
+    out.binaryNodes = (uint32_t)bin.size();
+    if (binRoot < 0) { out.rootRef = binRoot; return; }              // the whole scene is one leaf
+    Collapser col(bin);
+    col.computeHeights(binRoot);
+    col.out.reserve(bin.size() / 2 + 1);
+    uint32_t need = 0;
+    out.rootRef = col.emit(binRoot, kStackBudget, need);
+    out.stackNeed = need;
+    out.nodes.swap(col.out);
 }
 
 }  // namespace rth

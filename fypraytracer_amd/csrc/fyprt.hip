@@ -514,7 +514,7 @@ int fyprt_read_buffer(fyprt_context* c, int which, void* dst, size_t bytes) {
 int fyprt_reset_frame_index(fyprt_context* c) { if (!c) return FYPRT_EINVAL; c->frameIndex = 1; return FYPRT_OK; }
 uint32_t fyprt_frame_index(const fyprt_context* c) { return c ? c->frameIndex : 0; }
 
-int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void* tris48, uint32_t* tri_count, int32_t* root_ref, uint32_t* max_depth) {
+int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void* tris48, uint32_t* tri_count, int32_t* root_ref, uint32_t* max_stack) {
     if (!c) return FYPRT_EINVAL;
     if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_export_bvh before fyprt_upload_scene");
     const rth::SceneBVH& b = c->hostBvh;
@@ -523,7 +523,7 @@ int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void
     if (node_count) *node_count = (uint32_t)b.nodes.size();
     if (tri_count) *tri_count = (uint32_t)b.tris.size();
     if (root_ref) *root_ref = b.rootRef;
-    if (max_depth) *max_depth = b.maxDepth;
+    if (max_stack) *max_stack = b.stackNeed;
     return FYPRT_OK;
 }
 

@@ -91,26 +91,60 @@ struct Stack {
     RT_DEV int32_t pop() { --top; return lds[top * kBlock]; }
 };
 
-// Both child boxes of a node against one ray.  Same per-component IEEE operations as the scalar form
-// (plane - o) * (1/d) — the reference's slab formula, BVH.cuh:144-146 — but issued as packed fp32
-// (v_pk_add_f32 / v_pk_mul_f32, two planes per instruction): the node quads hold the planes as adjacent pairs
-// (lo.x lo.y | lo.z hi.x | hi.y hi.z), so the ray carries its origin / inverse direction in the matching (x,y), (z,x), (y,z) pairs.
+// One visit of a 4-wide node (layout: rt_host.h).  The child planes are never materialised: with the grid step s_a = 2^(e_a-127)
+// and the node origin g, the slab parameter of plane "g_a + q * s_a" is  t = q * (s_a / d_a) + (g_a - o_a) / d_a = fma(q, A_a, B_a),
+// A and B computed once per visit (s_a is a power of two, so A is exact), then 24 byte->float conversions and 24 fused
+// multiply-adds (issued as 12 v_pk_fma_f32) give the slabs of all four children.  Hit children are ordered by entry distance
+// with a 5-comparator network (ties keep slot order), the nearest is visited next and the others are pushed far-to-near.
+// Boxes are culled against `cut` (closest hit so far * 1.000001, or the light / visibility distance).
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct RayPk { v2f oxy, ozx, oyz, ixy, izx, iyz; };
-RT_DEV RayPk make_raypk(f3 o, float ix, float iy, float iz) {
-    RayPk r; r.oxy = v2f{o.x, o.y}; r.ozx = v2f{o.z, o.x}; r.oyz = v2f{o.y, o.z}; r.ixy = v2f{ix, iy}; r.izx = v2f{iz, ix}; r.iyz = v2f{iy, iz}; return r;
+struct RayPk { float ox, oy, oz, ix, iy, iz; };
+RT_DEV RayPk make_raypk(f3 o, float ix, float iy, float iz) { RayPk r; r.ox = o.x; r.oy = o.y; r.oz = o.z; r.ix = ix; r.iy = iy; r.iz = iz; return r; }
+RT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); }
+RT_DEV void slab_of_pair(v2f lx, v2f hx, v2f ly, v2f hy, v2f lz, v2f hz, float cut, float& n0, float& f0, float& n1, float& f1) {
+    n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx.x, hx.x), __builtin_fminf(ly.x, hy.x)), __builtin_fmaxf(__builtin_fminf(lz.x, hz.x), 0.0f));
+    f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx.x, hx.x), __builtin_fmaxf(ly.x, hy.x)), __builtin_fminf(__builtin_fmaxf(lz.x, hz.x), cut));
+    n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx.y, hx.y), __builtin_fminf(ly.y, hy.y)), __builtin_fmaxf(__builtin_fminf(lz.y, hz.y), 0.0f));
+    f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx.y, hx.y), __builtin_fmaxf(ly.y, hy.y)), __builtin_fminf(__builtin_fmaxf(lz.y, hz.y), cut));
 }
-RT_DEV void slab_pair(const float4 q0, const float4 q1, const float4 q2, const RayPk& r, float cut, float& n0, float& f0, float& n1, float& f1) {
-    const v2f a = (v2f{q0.x, q0.y} - r.oxy) * r.ixy;      // lo0.x lo0.y
-    const v2f b = (v2f{q0.z, q0.w} - r.ozx) * r.izx;      // lo0.z hi0.x
-    const v2f c = (v2f{q1.x, q1.y} - r.oyz) * r.iyz;      // hi0.y hi0.z
-    n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.y), __builtin_fminf(a.y, c.x)), __builtin_fmaxf(__builtin_fminf(b.x, c.y), 0.0f));
-    f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.y), __builtin_fmaxf(a.y, c.x)), __builtin_fminf(__builtin_fmaxf(b.x, c.y), cut));
-    const v2f d = (v2f{q1.z, q1.w} - r.oxy) * r.ixy;      // lo1.x lo1.y
-    const v2f e = (v2f{q2.x, q2.y} - r.ozx) * r.izx;      // lo1.z hi1.x
-    const v2f f = (v2f{q2.z, q2.w} - r.oyz) * r.iyz;      // hi1.y hi1.z
-    n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d.x, e.y), __builtin_fminf(d.y, f.x)), __builtin_fmaxf(__builtin_fminf(e.x, f.y), 0.0f));
-    f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d.x, e.y), __builtin_fmaxf(d.y, f.x)), __builtin_fminf(__builtin_fmaxf(e.x, f.y), cut));
+RT_DEV void order_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb; const int32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+// returns the next reference to visit (a child, or the popped stack top when no child is hit)
+RT_DEV int32_t node_step(const float4* nodes, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, bool counting) {
+    const float4* n = nodes + (size_t)cur * 4;
+    const float4 q0 = n[0], q1 = n[1], q2 = n[2];
+    const float2 q3 = *reinterpret_cast<const float2*>(n + 3);
+    const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = ex >> 24;
+    if (counting) nBox += cnt;
+    const float Ax = __int_as_float((int)((ex & 0xFFu) << 23)) * r.ix, Ay = __int_as_float((int)(((ex >> 8) & 0xFFu) << 23)) * r.iy,
+                Az = __int_as_float((int)(((ex >> 16) & 0xFFu) << 23)) * r.iz;
+    const float Bx = (q0.x - r.ox) * r.ix, By = (q0.y - r.oy) * r.iy, Bz = (q0.z - r.oz) * r.iz;
+    const v2f Ax2 = v2f{Ax, Ax}, Ay2 = v2f{Ay, Ay}, Az2 = v2f{Az, Az}, Bx2 = v2f{Bx, Bx}, By2 = v2f{By, By}, Bz2 = v2f{Bz, Bz};
+    const uint32_t lx = (uint32_t)__float_as_int(q2.x), ly = (uint32_t)__float_as_int(q2.y), lz = (uint32_t)__float_as_int(q2.z),
+                   hx = (uint32_t)__float_as_int(q2.w), hy = (uint32_t)__float_as_int(q3.x), hz = (uint32_t)__float_as_int(q3.y);
+    float k0, k1, k2, k3, f0, f1, f2, f3_;
+    slab_of_pair(__builtin_elementwise_fma(v2f{ubyte_f(lx, 0), ubyte_f(lx, 1)}, Ax2, Bx2), __builtin_elementwise_fma(v2f{ubyte_f(hx, 0), ubyte_f(hx, 1)}, Ax2, Bx2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(ly, 0), ubyte_f(ly, 1)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(hy, 0), ubyte_f(hy, 1)}, Ay2, By2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(lz, 0), ubyte_f(lz, 1)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(hz, 0), ubyte_f(hz, 1)}, Az2, Bz2),
+                 cut, k0, f0, k1, f1);
+    slab_of_pair(__builtin_elementwise_fma(v2f{ubyte_f(lx, 2), ubyte_f(lx, 3)}, Ax2, Bx2), __builtin_elementwise_fma(v2f{ubyte_f(hx, 2), ubyte_f(hx, 3)}, Ax2, Bx2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(ly, 2), ubyte_f(ly, 3)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(hy, 2), ubyte_f(hy, 3)}, Ay2, By2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(lz, 2), ubyte_f(lz, 3)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(hz, 2), ubyte_f(hz, 3)}, Az2, Bz2),
+                 cut, k2, f2, k3, f3_);
+    const float kMissKey = __builtin_inff();
+    k0 = (k0 <= f0) ? k0 : kMissKey;                                  // slots 0 and 1 are always valid (count >= 2)
+    k1 = (k1 <= f1) ? k1 : kMissKey;
+    k2 = (k2 <= f2 && cnt > 2u) ? k2 : kMissKey;
+    k3 = (k3 <= f3_ && cnt > 3u) ? k3 : kMissKey;
+    int32_t r0 = __float_as_int(q1.x), r1 = __float_as_int(q1.y), r2 = __float_as_int(q1.z), r3 = __float_as_int(q1.w);
+    order_pair(k0, r0, k1, r1); order_pair(k2, r2, k3, r3); order_pair(k0, r0, k2, r2); order_pair(k1, r1, k3, r3); order_pair(k1, r1, k2, r2);
+    if (k3 < kMissKey) st.push(r3);
+    if (k2 < kMissKey) st.push(r2);
+    if (k1 < kMissKey) st.push(r1);
+    return (k0 < kMissKey) ? r0 : st.pop();
 }
 
 RT_DEV float safe_inv(float d) { return 1.0f / ((__builtin_fabsf(d) < 1e-30f) ? __builtin_copysignf(1e-30f, d) : d); }
@@ -130,20 +164,7 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     int32_t cur = sc.rootRef;
     while (true) {
         while (cur >= 0) {
-            const float4* n = sc.nodes + (size_t)cur * 4;
-            const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            if (counting) nBox += 2;
-            float n0, f0, n1, f1;
-            slab_pair(q0, q1, q2, pk, closestInfl, n0, f0, n1, f1);
-            const bool h0 = n0 <= f0, h1 = n1 <= f1;
-            const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool swap = n1 < n0;
-                st.push(swap ? c0 : c1);
-                cur = swap ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else cur = st.pop();
+            cur = node_step(sc.nodes, cur, pk, closestInfl, st, nBox, counting);
             // lanes that reached a leaf wait outside this loop; once only a few lanes are still walking inner nodes,
             // stop and let everybody test their leaves (keeps SIMD lanes busy; pure scheduling, results unchanged)
             if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
@@ -218,17 +239,7 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
     bool occluded = false;
     while (!occluded) {
         while (cur >= 0) {
-            const float4* n = sc.nodes + (size_t)cur * 4;
-            const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            if (counting) nBox += 2;
-            float n0, f0, n1, f1;
-            slab_pair(q0, q1, q2, pk, cut, n0, f0, n1, f1);
-            const bool h0 = n0 <= f0, h1 = n1 <= f1;
-            const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) { const bool swap = n1 < n0; st.push(swap ? c0 : c1); cur = swap ? c1 : c0; }
-            else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else cur = st.pop();
+            cur = node_step(sc.nodes, cur, pk, cut, st, nBox, counting);
             if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
         }
         if (cur >= 0) continue;
@@ -276,17 +287,7 @@ RT_DEV bool trace_visible(const DevScene& sc, f3 o, f3 d, float dist, float tol,
         int32_t cur = sc.rootRef;
         while (!blocked) {
             while (cur >= 0) {
-                const float4* n = sc.nodes + (size_t)cur * 4;
-                const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                if (counting) nBox += 2;
-                float n0, f0, n1, f1;
-                slab_pair(q0, q1, q2, pk, cut, n0, f0, n1, f1);
-                const bool h0 = n0 <= f0, h1 = n1 <= f1;
-                const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                if (h0 && h1) { const bool swap = n1 < n0; st.push(swap ? c0 : c1); cur = swap ? c1 : c0; }
-                else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else cur = st.pop();
+                cur = node_step(sc.nodes, cur, pk, cut, st, nBox, counting);
                 if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
             }
             if (cur >= 0) continue;

@@ -7,25 +7,33 @@
 
 namespace rth {
 
-// 64-byte node = four 16-byte quads, both child boxes in the parent so one node fetch
-// (4 x global_load_dwordx4) decides both children.
-//   q0 = lo0.x lo0.y lo0.z hi0.x | q1 = hi0.y hi0.z lo1.x lo1.y | q2 = lo1.z hi1.x hi1.y hi1.z | q3 = child0 child1 pad pad
+// 64-byte 4-wide node = four 16-byte quads; the child boxes are quantised to 8 bits per plane on a power-of-two grid
+// anchored at the node's own box, so ONE node fetch (4 x global_load_dwordx4) decides up to four children:
+//   q0 = origin.x origin.y origin.z (ex | ey << 8 | ez << 16 | count << 24)     grid step on axis a = 2^(e_a - 127)
+//   q1 = child[0..3]
+//   q2 = qlo.x[0..3] qlo.y[0..3] qlo.z[0..3] qhi.x[0..3]                        one byte per child, child i = byte i
+//   q3 = qhi.y[0..3] qhi.z[0..3] pad pad
+// plane = origin_a + q * 2^(e_a - 127); lo planes are rounded down and hi planes up (with 1/16 step of slack), so the
+// quantised box always contains the exact child box.  Children 0..count-1 are valid, count in 2..4.
 // child >= 0: inner node index.  child < 0: leaf, ~child = (firstTri << 2) | (count - 1), count 1..4.
-struct Node { float lo0[3], hi0[3], lo1[3], hi1[3]; int32_t child0, child1, pad[2]; };
+struct Node { float origin[3]; uint8_t ex[3]; uint8_t count; int32_t child[4]; uint8_t qlo[3][4]; uint8_t qhi[3][4]; uint32_t pad[2]; };
 // 48-byte leaf triangle = three quads: v0.xyz e1.x | e1.yz e2.xy | e2.z tri pad pad  (e1 = v1 - v0, e2 = v2 - v0)
 struct Tri { float v0[3], e1[3], e2[3]; uint32_t tri, pad[2]; };
 static_assert(sizeof(Node) == 64 && sizeof(Tri) == 48, "layout");
 
 struct SceneBVH {
-    std::vector<Node> nodes;   // TLAS nodes first, then each mesh's BLAS
+    std::vector<Node> nodes;   // pre-order: the top of the tree is contiguous
     std::vector<Tri> tris;     // leaf order
     int32_t rootRef = 0;       // inner index or leaf code
-    uint32_t maxDepth = 0;     // deepest leaf (root = depth 0) -> traversal stack bound
-    uint32_t tlasNodes = 0;
+    uint32_t maxDepth = 0;     // deepest leaf of the binary SAH tree the wide tree is collapsed from (root = depth 0)
+    uint32_t stackNeed = 0;    // worst-case number of pending stack entries of an ordered traversal (<= kStackBudget by construction)
+    uint32_t binaryNodes = 0;  // inner nodes of the binary tree before the collapse
 };
 
+constexpr uint32_t kStackBudget = 31;   // kernels: 32-entry LDS stack, one entry is the exit sentinel
 // Two-level build: one SAH BLAS per mesh (world-space triangles, <= 4 per leaf) and a SAH TLAS
-// over the mesh bounds whose leaves are the BLAS roots.  Replaces BVH::ConstructBVH_SAH
+// over the mesh bounds whose leaves are the BLAS roots, merged into one binary tree and then collapsed
+// into 4-wide nodes with quantised child boxes.  Replaces BVH::ConstructBVH_SAH
 // (BVH.cpp:65-81) + Mesh::CreateBVHnodesFromMeshTriangles / Scene::CreateBVHnodesFromSceneMeshes.
 void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
                    uint32_t meshCount, SceneBVH& out);

@@ -234,17 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
         while (true) {
             // inner nodes
             while (active && r.cur >= 0) {
-                const float4* n = sc.nodes + (size_t)r.cur * 4;
-                const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                if (counting) r.nBox += 2;
-                float n0, f0, n1, f1;
-                slab_pair(q0, q1, q2, r.pk, r.cut, n0, f0, n1, f1);
-                const bool h0 = n0 <= f0, h1 = n1 <= f1;
-                const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                if (h0 && h1) { const bool swap = n1 < n0; lane_push(lds, r.top, swap ? c0 : c1); r.cur = swap ? c1 : c0; }
-                else if (h0) r.cur = c0;
-                else if (h1) r.cur = c1;
-                else r.cur = lane_pop(lds, r.top);
+                { Stack st; st.lds = lds; st.top = r.top; r.cur = node_step(sc.nodes, r.cur, r.pk, r.cut, st, r.nBox, counting); r.top = st.top; }
                 if ((uint32_t)__popcll(__ballot(r.cur >= 0)) < sc.nodeQuorum) break;
             }
             // leaves

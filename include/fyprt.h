@@ -218,9 +218,13 @@ uint32_t fyprt_frame_index(const fyprt_context* ctx);
 
 /* Export of the library's own acceleration structure as plain arrays, so an
  * instrumented CPU restatement of the same traversal can count box / triangle tests
- * (SURVEY.md §8d).  Call with NULL pointers to query the counts. */
+ * (SURVEY.md §8d).  Call with NULL pointers to query the counts.
+ *   nodes64: 64-byte 4-wide nodes { float origin[3]; uint8 ex[3], count; int32 child[4]; uint8 qlo[3][4], qhi[3][4]; uint32 pad[2] }
+ *            child plane on axis a = origin[a] + q * 2^(ex[a]-127); child >= 0 inner node, < 0 leaf: ~child = firstTri << 2 | (n-1)
+ *   tris48 : 48-byte leaf triangles { float v0[3], e1[3], e2[3]; uint32 triangleIndex; uint32 pad[2] }
+ *   max_stack: worst-case number of pending traversal-stack entries of an ordered traversal (<= 31 by construction). */
 int fyprt_export_bvh(fyprt_context* ctx, void* nodes64, uint32_t* node_count, void* tris48,
-                     uint32_t* tri_count, int32_t* root_ref, uint32_t* max_depth);
+                     uint32_t* tri_count, int32_t* root_ref, uint32_t* max_stack);
 /* Export of the light trees the library built (same flat node format as the input). */
 int fyprt_export_lighttrees(fyprt_context* ctx, fyprt_lighttree_node* tlas, uint32_t* tlas_count, uint32_t* tlas_root,
                             fyprt_lighttree_node* blas, uint32_t* blas_total, uint32_t* blas_first,

@@ -7,18 +7,21 @@
 // restatement of that traversal on the identical scene/camera/seed" — this is that
 // restatement.  It consumes DATA produced by the product (node / triangle arrays); it
 // shares no code with it.  Layout contract:
-//   node  (64 B): float lo0[3], hi0[3], lo1[3], hi1[3]; int32 child0, child1; int32 pad[2]
+//   node  (64 B): float origin[3]; uint8 ex[3], count; int32 child[4]; uint8 qlo[3][4], qhi[3][4]; uint32 pad[2]
+//                 child plane on axis a = origin[a] + q * 2^(ex[a] - 127); children 0..count-1 valid
 //   child >= 0 : inner node index;  child < 0 : leaf, ~child = (firstTri << 2) | (count-1)
 //   tri   (48 B): float v0[3], e1[3], e2[3]; uint32 triangleIndex; uint32 pad[2]
-// Traversal: ordered (near child first, ties -> child0), far child pushed, boxes culled
-// against closest*1.000001f, slab test (plane - o) * (1/d) with |d| < 1e-30 replaced by
-// copysign(1e-30, d); Möller–Trumbore identical to Renderer.cu:513-537 on (v0, e1, e2).
+// Traversal: per visit A_a = 2^(ex_a-127) * (1/d_a), B_a = (origin_a - o_a) * (1/d_a), slab parameter of a plane
+// t = fma(q, A_a, B_a); children culled against cut (= closest*1.000001f, or the light / visibility distance); hit
+// children ordered by entry distance with the 5-comparator network (0,1)(2,3)(0,2)(1,3)(1,2), strict "<" so ties keep
+// slot order; nearest visited next, the others pushed far-to-near; |d| < 1e-30 replaced by copysign(1e-30, d);
+// Möller–Trumbore identical to Renderer.cu:513-537 on (v0, e1, e2).
 #pragma once
 #include "oracle_render.h"
 
 namespace orc {
 
-struct PNode { float lo0[3], hi0[3], lo1[3], hi1[3]; int32_t child0, child1, pad[2]; };
+struct PNode { float origin[3]; uint8_t ex[3], count; int32_t child[4]; uint8_t qlo[3][4], qhi[3][4]; uint32_t pad[2]; };
 struct PTri { float v0[3], e1[3], e2[3]; uint32_t tri, pad[2]; };
 static_assert(sizeof(PNode) == 64 && sizeof(PTri) == 48, "layout");
 
@@ -26,6 +29,30 @@ struct ProductTracer : Tracer {
     const Scene& sc; std::vector<PNode> nodes; std::vector<PTri> tris; int32_t rootRef = 0;
     explicit ProductTracer(const Scene& s) : sc(s) {}
     static inline float safeInv(float d) { return 1.0f / ((fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d); }
+    static inline float pow2e(uint8_t e) { uint32_t b = (uint32_t)e << 23; float f; memcpy(&f, &b, 4); return f; }
+    // one node visit: pushes the hit children far-to-near, returns true and the nearest in `next` if any child is hit
+    bool Visit(const PNode& n, float ox, float oy, float oz, float ix, float iy, float iz, float cut, int32_t* stack, int& top, int32_t& next, Counters& c) const {
+        c.boxTests += n.count;
+        const float o[3] = {ox, oy, oz}, inv[3] = {ix, iy, iz};
+        float A[3], B[3];
+        for (int a = 0; a < 3; ++a) { A[a] = pow2e(n.ex[a]) * inv[a]; B[a] = (n.origin[a] - o[a]) * inv[a]; }
+        float key[4]; int32_t ref[4];
+        for (int i = 0; i < 4; ++i) {
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) { lo[a] = fmaf((float)n.qlo[a][i], A[a], B[a]); hi[a] = fmaf((float)n.qhi[a][i], A[a], B[a]); }
+            float tnear = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), 0.0f));
+            float tfar = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fminf(fmaxf(lo[2], hi[2]), cut));
+            key[i] = (tnear <= tfar && i < (int)n.count) ? tnear : INFINITY;
+            ref[i] = n.child[i];
+        }
+        auto order = [&](int a, int b) { if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(ref[a], ref[b]); } };
+        order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+        if (key[3] < INFINITY) stack[top++] = ref[3];
+        if (key[2] < INFINITY) stack[top++] = ref[2];
+        if (key[1] < INFINITY) stack[top++] = ref[1];
+        if (key[0] < INFINITY) { next = ref[0]; return true; }
+        return false;
+    }
     Payload Trace(const Ray& ray, Counters& c) const override {
         c.rays++;
         if (tris.empty()) return Miss();
@@ -33,24 +60,9 @@ struct ProductTracer : Tracer {
         const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
         float closest = FLT_MAX, closestInfl = closest * 1.000001f; int closestTri = -1; float cu = 0.0f, cv = 0.0f;
         int32_t stack[128]; int top = 0; int32_t cur = rootRef;
-        auto slab = [&](const float* lo, const float* hi, float& tn) -> bool {
-            float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
-            float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
-            float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
-            float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closestInfl));
-            tn = tnear; return tnear <= tfar;
-        };
         while (true) {
             if (cur >= 0) {
-                const PNode& n = nodes[cur];
-                c.boxTests += 2;
-                float t0, t1; bool h0 = slab(n.lo0, n.hi0, t0), h1 = slab(n.lo1, n.hi1, t1);
-                if (h0 && h1) {
-                    if (t1 < t0) { stack[top++] = n.child0; cur = n.child1; } else { stack[top++] = n.child1; cur = n.child0; }
-                    continue;
-                } else if (h0) { cur = n.child0; continue; }
-                else if (h1) { cur = n.child1; continue; }
+                if (Visit(nodes[cur], ox, oy, oz, ix, iy, iz, closestInfl, stack, top, cur, c)) continue;
             } else {
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -100,23 +112,10 @@ struct ProductTracer : Tracer {
         const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
         const float cut = tL * 1.000001f;
         int32_t stack[128]; int top = 0; int32_t cur = rootRef;
-        auto slab = [&](const float* lo, const float* hi, float& tn) -> bool {
-            float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
-            float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
-            float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
-            float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), cut));
-            tn = tnear; return tnear <= tfar;
-        };
         Payload r = Miss(); r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
         while (true) {
             if (cur >= 0) {
-                const PNode& n = nodes[cur];
-                c.boxTests += 2;
-                float t0, t1; bool h0 = slab(n.lo0, n.hi0, t0), h1 = slab(n.lo1, n.hi1, t1);
-                if (h0 && h1) { if (t1 < t0) { stack[top++] = n.child0; cur = n.child1; } else { stack[top++] = n.child1; cur = n.child0; } continue; }
-                else if (h0) { cur = n.child0; continue; }
-                else if (h1) { cur = n.child1; continue; }
+                if (Visit(nodes[cur], ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
             } else {
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -151,22 +150,9 @@ struct ProductTracer : Tracer {
             const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
             const float tLo = dist - tol, tHi = dist + tol, cut = tHi * 1.000001f;
             int32_t stack[128]; int top = 0; int32_t cur = rootRef;
-            auto slab = [&](const float* lo, const float* hi, float& tn) -> bool {
-                float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
-                float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
-                float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
-                float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-                float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), cut));
-                tn = tnear; return tnear <= tfar;
-            };
             while (true) {
                 if (cur >= 0) {
-                    const PNode& n = nodes[cur];
-                    c.boxTests += 2;
-                    float t0, t1; bool h0 = slab(n.lo0, n.hi0, t0), h1 = slab(n.lo1, n.hi1, t1);
-                    if (h0 && h1) { if (t1 < t0) { stack[top++] = n.child0; cur = n.child1; } else { stack[top++] = n.child1; cur = n.child0; } continue; }
-                    else if (h0) { cur = n.child0; continue; }
-                    else if (h1) { cur = n.child1; continue; }
+                    if (Visit(nodes[cur], ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
                 } else {
                     uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                     for (uint32_t k = 0; k < cnt; ++k) {

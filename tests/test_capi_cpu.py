@@ -75,7 +75,7 @@ def test_bvh_invariants(name):
     b = ctx.export_bvh()
     nodes, tris = b["nodes"], b["tris"]
     assert sorted(tris["tri"].tolist()) == list(range(len(sc.triangles)))   # every triangle exactly once
-    assert b["max_depth"] + 2 <= 32                                          # fits the 32-entry LDS traversal stack
+    assert b["max_stack"] + 1 <= 32                                          # fits the 32-entry LDS traversal stack (one entry = exit sentinel)
     pos = sc.world_vertices["position"]
     t = sc.triangles
     # leaf records are (v0, v1 - v0, v2 - v0) of the original triangle, bit for bit
@@ -87,24 +87,34 @@ def test_bvh_invariants(name):
     tri_lo = np.minimum(np.minimum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
     tri_hi = np.maximum(np.maximum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
     seen = np.zeros(len(nodes), dtype=int)
+    assert ((nodes["count"] >= 2) & (nodes["count"] <= 4)).all()
 
     def bounds(ref):
+        """-> (lo, hi, stack need) of the subtree; checks that every quantised child box contains everything below it."""
         if ref >= 0:
             seen[ref] += 1
             n = nodes[ref]
-            l0, h0 = bounds(int(n["child0"]))
-            l1, h1 = bounds(int(n["child1"]))
-            assert (n["lo0"] <= l0).all() and (n["hi0"] >= h0).all() and (n["lo1"] <= l1).all() and (n["hi1"] >= h1).all()
-            return np.minimum(n["lo0"], n["lo1"]), np.maximum(n["hi0"], n["hi1"])
+            k = int(n["count"])
+            step = np.ldexp(np.float32(1.0), n["ex"].astype(np.int32) - 127).astype(np.float32)
+            lo_all, hi_all, need = [], [], 0
+            for i in range(k):
+                l, h, cn = bounds(int(n["child"][i]))
+                qlo = (n["origin"] + n["qlo"][:, i].astype(np.float32) * step).astype(np.float32)   # exact: q * 2^e, then one rounding
+                qhi = (n["origin"] + n["qhi"][:, i].astype(np.float32) * step).astype(np.float32)
+                assert (qlo <= l).all() and (qhi >= h).all()
+                lo_all.append(l); hi_all.append(h); need = max(need, cn)
+            assert (n["origin"] == np.min(lo_all, axis=0)).all()                                      # grid anchored at the node's own box
+            return np.min(lo_all, axis=0), np.max(hi_all, axis=0), (k - 1) + need
         code = ~ref
         first, cnt = code >> 2, (code & 3) + 1
         ids = tris["tri"][first:first + cnt]
-        return tri_lo[ids].min(0), tri_hi[ids].max(0)
+        return tri_lo[ids].min(0), tri_hi[ids].max(0), 0
 
     import sys
     sys.setrecursionlimit(10000)
-    bounds(b["root"])
+    _, _, need = bounds(b["root"])
     assert (seen == 1).all()
+    assert need == b["max_stack"] <= 31
     ctx.close()
 
 
@@ -128,7 +138,7 @@ def test_bvh_depth_is_bounded_by_construction():
     ctx = capi.Context(-1)
     ctx.upload_scene(sc)
     b = ctx.export_bvh()
-    assert b["max_depth"] + 2 <= 32
+    assert b["max_stack"] + 1 <= 32
     assert sorted(b["tris"]["tri"].tolist()) == list(range(n))
     ctx.close()
 
