@@ -46,7 +46,7 @@ LT_NODE_DTYPE = np.dtype([("energy", "<f4"), ("numEmitters", "<u4"), ("left", "<
                           ("boxLo", "<f4", 3), ("boxHi", "<f4", 3), ("boxCentroid", "<f4", 3), ("_pad", "<u4")])
 assert VERTEX_DTYPE.itemsize == 32 and TRIANGLE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 44
 assert MESH_DTYPE.itemsize == 12 and LT_NODE_DTYPE.itemsize == 80
-BVH_NODE_DTYPE = np.dtype([("origin", "<f4", 3), ("ex", "u1", 3), ("count", "u1"), ("child", "<i4", 4),
+BVH_NODE_DTYPE = np.dtype([("origin", "<f4", 3), ("ex", "u1", 3), ("meta", "u1"), ("child", "<i4", 4),
                            ("qlo", "u1", (3, 4)), ("qhi", "u1", (3, 4)), ("pad", "<u4", 2)])
 BVH_TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("tri", "<u4"), ("pad", "<u4", 2)])
 assert BVH_NODE_DTYPE.itemsize == 64 and BVH_TRI_DTYPE.itemsize == 48

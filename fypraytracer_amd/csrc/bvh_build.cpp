@@ -9,8 +9,11 @@
 // triangles a ray can reach is the same, and the closest hit is found with the reference's
 // own Möller–Trumbore arithmetic, so results match except for exact-tie order.
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include "rt_host.h"
@@ -100,24 +103,57 @@ struct Builder {
 
 
 // ---- collapse of the binary tree into 4-wide nodes ------------------------------------------------------------
-// Greedy: starting from a binary node's two children, the child with the largest surface area is replaced by its own
-// two children until there are four (or only leaves are left).  Stack safety is kept BY CONSTRUCTION: an ordered traversal
-// of a k-wide node leaves up to k-1 siblings pending, so a node with stack budget b may only become k wide if every child
-// still fits its binary subtree into b - (k-1) (binary height is the fallback that always fits: one pending entry per level).
+// Which descendants become the (up to four) children of a wide node is decided by a dynamic programme that minimises the
+// summed surface area of the wide nodes (below).  Every node records how many wide levels its subtree has: the traversal
+// pushes the siblings it does not visit next one by one while  pending + 2 + levels <= kStackBudget  and otherwise a
+// single "resume this node" entry (rt_device.h: node_step), so the pending-entry count can never exceed
+// kStackBudget as long as the tree has at most kStackBudget levels — which the binary depth bound (kMaxDepth) implies.
 struct Collapser {
-    const std::vector<Node2>& bn; std::vector<uint8_t> height; std::vector<Node> out; uint32_t stackNeed = 0;
-    explicit Collapser(const std::vector<Node2>& b) : bn(b), height(b.size(), 0) {}
+    const std::vector<Node2>& bn; std::vector<uint8_t> height; std::vector<Node> out;
+    // SAH-optimal collapse (dynamic programme over the binary tree): cost[n][j-1] = least sum of wide-node surface areas that
+    // covers the subtree of binary node n with at most j roots (a root is a wide node or a leaf reference); sel[n][j-1] = how
+    // the j roots are dealt to the two children ({0,0} = "n itself is the one root").  The expected number of node visits of a
+    // random ray is proportional to that sum and the leaves are fixed, so this is the cheapest 4-wide tree obtainable from
+    // the binary one.
+    struct Child { int32_t ref; Box b; };
+    struct Sel { uint8_t j0, j1; };
+    std::vector<std::array<float, 4>> cost; std::vector<std::array<Sel, 4>> sel;
+    explicit Collapser(const std::vector<Node2>& b) : bn(b), height(b.size(), 0), cost(b.size()), sel(b.size()) {}
+    float T(int32_t ref, int j) const { return ref < 0 ? 0.0f : cost[(size_t)ref][j - 1]; }
+    void solve(int32_t ref) {
+        if (ref < 0) return;
+        const Node2& b = bn[ref];
+        solve(b.child0); solve(b.child1);
+        Box nb; nb.grow(b.lo0, b.hi0); nb.grow(b.lo1, b.hi1);
+        auto& c = cost[(size_t)ref]; auto& sp = sel[(size_t)ref];
+        float best[5]; Sel arg[5];
+        for (int j = 2; j <= 4; ++j) {
+            best[j] = FLT_MAX; arg[j] = Sel{1, (uint8_t)(j - 1)};
+            for (int j0 = 1; j0 < j; ++j0) { const float v = T(b.child0, j0) + T(b.child1, j - j0); if (v < best[j]) { best[j] = v; arg[j] = Sel{(uint8_t)j0, (uint8_t)(j - j0)}; } }
+        }
+        c[0] = nb.area() + best[4]; sp[0] = Sel{0, 0};
+        for (int j = 2; j <= 4; ++j) {
+            if (c[j - 2] <= best[j]) { c[j - 1] = c[j - 2]; sp[j - 1] = sp[j - 2]; }      // "at most j": fewer roots are allowed
+            else { c[j - 1] = best[j]; sp[j - 1] = arg[j]; }
+        }
+    }
+    // the roots the programme chooses for (ref, at most j roots), appended to ch[] with their boxes
+    void roots(int32_t ref, const Box& box, int j, Child* ch, int& k) const {
+        if (ref < 0 || sel[(size_t)ref][j - 1].j0 == 0) { ch[k].ref = ref; ch[k].b = box; ++k; return; }
+        const Sel s = sel[(size_t)ref][j - 1];
+        const Node2& b = bn[ref]; Box b0, b1; std::memcpy(b0.lo, b.lo0, 12); std::memcpy(b0.hi, b.hi0, 12); std::memcpy(b1.lo, b.lo1, 12); std::memcpy(b1.hi, b.hi1, 12);
+        roots(b.child0, b0, s.j0, ch, k); roots(b.child1, b1, s.j1, ch, k);
+    }
     uint32_t h(int32_t ref) const { return ref < 0 ? 0u : height[(size_t)ref]; }
     uint32_t computeHeights(int32_t ref) {
         if (ref < 0) return 0;
         const uint32_t v = 1u + std::max(computeHeights(bn[ref].child0), computeHeights(bn[ref].child1));
         height[(size_t)ref] = (uint8_t)v; return v;
     }
-    struct Child { int32_t ref; Box b; };
     static void quantise(Node& n, const Child* ch, int k) {
         Box nb; for (int i = 0; i < k; ++i) nb.grow(ch[i].b);
         std::memset(&n, 0, sizeof n);
-        n.count = (uint8_t)k;
+        n.meta = (uint8_t)k;
         for (int a = 0; a < 3; ++a) {
             const float lo = nb.lo[a]; n.origin[a] = lo;
             const double ext = (double)nb.hi[a] - (double)lo;
@@ -139,41 +175,26 @@ struct Collapser {
             n.ex[a] = (uint8_t)e;
         }
     }
-    // returns the wide index; `need` = worst-case pending entries below (and including) this node
-    int32_t emit(int32_t ref, uint32_t budget, uint32_t& need) {
-        Child ch[4]; int k = 2;
-        { const Node2& b = bn[ref]; ch[0].ref = b.child0; std::memcpy(ch[0].b.lo, b.lo0, 12); std::memcpy(ch[0].b.hi, b.hi0, 12);
-          ch[1].ref = b.child1; std::memcpy(ch[1].b.lo, b.lo1, 12); std::memcpy(ch[1].b.hi, b.hi1, 12); }
-        while (k < 4) {
-            int best = -1; float bestArea = -1.0f;
-            for (int i = 0; i < k; ++i) {
-                if (ch[i].ref < 0) continue;
-                bool fits = true;                                            // k + 1 children -> child budget = budget - k
-                for (int j = 0; j < k && fits; ++j) if (j != i && h(ch[j].ref) + (uint32_t)k > budget) fits = false;
-                const Node2& c = bn[ch[i].ref];
-                if (h(c.child0) + (uint32_t)k > budget || h(c.child1) + (uint32_t)k > budget) fits = false;
-                if (!fits) continue;
-                const float ar = ch[i].b.area();
-                if (ar > bestArea) { bestArea = ar; best = i; }
-            }
-            if (best < 0) break;
-            const Node2& c = bn[ch[best].ref];
-            for (int j = k; j > best + 1; --j) ch[j] = ch[j - 1];              // the two grandchildren take the child's place
-            ch[best].ref = c.child0; std::memcpy(ch[best].b.lo, c.lo0, 12); std::memcpy(ch[best].b.hi, c.hi0, 12);
-            ch[best + 1].ref = c.child1; std::memcpy(ch[best + 1].b.lo, c.lo1, 12); std::memcpy(ch[best + 1].b.hi, c.hi1, 12);
-            ++k;
-        }
+    // returns the wide index; `levels` = wide levels of the subtree rooted here (1 = all children are leaves)
+    int32_t emit(int32_t ref, uint32_t& levels) {
+        Child ch[4]; int k = 0;
+        const Node2& bnode = bn[ref];
+        Box b0, b1; std::memcpy(b0.lo, bnode.lo0, 12); std::memcpy(b0.hi, bnode.hi0, 12); std::memcpy(b1.lo, bnode.lo1, 12); std::memcpy(b1.hi, bnode.hi1, 12);
+        float best = FLT_MAX; int bj0 = 1;
+        for (int j0 = 1; j0 < 4; ++j0) { const float v = T(bnode.child0, j0) + T(bnode.child1, 4 - j0); if (v < best) { best = v; bj0 = j0; } }
+        roots(bnode.child0, b0, bj0, ch, k); roots(bnode.child1, b1, 4 - bj0, ch, k);
         const int32_t self = (int32_t)out.size();
         out.emplace_back();
         Node n; quantise(n, ch, k);
         uint32_t below = 0;
         for (int i = 0; i < k; ++i) {
-            if (ch[i].ref >= 0) { uint32_t cn = 0; n.child[i] = emit(ch[i].ref, budget - (uint32_t)(k - 1), cn); below = std::max(below, cn); }
+            if (ch[i].ref >= 0) { uint32_t cl = 0; n.child[i] = emit(ch[i].ref, cl); below = std::max(below, cl); }
             else n.child[i] = ch[i].ref;
         }
-        for (int i = k; i < 4; ++i) n.child[i] = INT32_MIN;                       // never read: count masks the slot
+        for (int i = k; i < 4; ++i) n.child[i] = INT32_MIN;                       // never read: the count masks the slot
+        levels = 1u + below;
+        n.meta = (uint8_t)((uint32_t)k | (levels << 3));
         out[(size_t)self] = n;
-        need = (uint32_t)(k - 1) + below;
         return self;
     }
 };
@@ -264,10 +285,12 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
     if (binRoot < 0) { out.rootRef = binRoot; return; }              // the whole scene is one leaf
     Collapser col(bin);
     col.computeHeights(binRoot);
+    col.solve(binRoot);
     col.out.reserve(bin.size() / 2 + 1);
-    uint32_t need = 0;
-    out.rootRef = col.emit(binRoot, kStackBudget, need);
-    out.stackNeed = need;
+    uint32_t levels = 0;
+    out.rootRef = col.emit(binRoot, levels);
+    out.levels = levels;
+    if (std::getenv("FYPRT_BVH_DEBUG")) std::fprintf(stderr, "[bvh] binary nodes %zu height %u, wide nodes %zu, wide levels %u, tris %zu\n", bin.size(), col.h(binRoot), col.out.size(), levels, out.tris.size());
     out.nodes.swap(col.out);
 }
 

@@ -59,7 +59,7 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[8] = {2, 1, 5, 0, 128, 24, 16, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[9] = {2, 1, 5, 0, 128, 24, 16, 0, 31};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
@@ -190,8 +190,9 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     struct HostOnlyGuard { bool prev; explicit HostOnlyGuard(bool on) : prev(g_hostOnlyAlloc) { g_hostOnlyAlloc = on; } ~HostOnlyGuard() { g_hostOnlyAlloc = prev; } } guard(c->hostOnly);
     // acceleration structure (ours)
     rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
-    if (c->hostBvh.maxDepth + 2 > (uint32_t)kStackDepth)
-        return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: BVH depth " + std::to_string(c->hostBvh.maxDepth) + " exceeds the traversal stack");
+    if (c->hostBvh.levels > rth::kStackBudget || c->hostBvh.nodes.size() >= (size_t)(1u << 26))
+        return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: acceleration structure (" + std::to_string(c->hostBvh.levels) + " levels, " +
+                       std::to_string(c->hostBvh.nodes.size()) + " nodes) exceeds the traversal stack / node index range");
     HIPCHK(c, c->nodes.alloc(c->hostBvh.nodes.size() * 4)); HIPCHK(c, c->leafTris.alloc(c->hostBvh.tris.size() * 3));
     if (upload(c, c->nodes.p, c->hostBvh.nodes.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
     // per-triangle gather records
@@ -338,6 +339,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
     c->dsc.nodeQuorum = (uint32_t)c->tuning[7];                 // 0 by default: measured best for every fused per-pixel kernel
+    c->dsc.stackBudget = std::min((int)rth::kStackBudget, std::max((int)c->hostBvh.levels, c->tuning[8]));   // never below the level count: node_step's induction
     if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
@@ -523,7 +525,7 @@ int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void
     if (node_count) *node_count = (uint32_t)b.nodes.size();
     if (tri_count) *tri_count = (uint32_t)b.tris.size();
     if (root_ref) *root_ref = b.rootRef;
-    if (max_stack) *max_stack = b.stackNeed;
+    if (max_stack) *max_stack = b.levels;
     return FYPRT_OK;
 }
 
@@ -544,7 +546,7 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 8) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 9) return FYPRT_EINVAL;
     c->tuning[key] = value;
     return FYPRT_OK;
 }

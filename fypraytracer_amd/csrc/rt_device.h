@@ -27,6 +27,7 @@ struct DevScene {
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
     const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot; const uint32_t* ltLeafOfTri;
     unsigned long long* rayCounter;   // nullptr = counting off; else [0] rays [1] box tests [2] triangle tests [3] hits
+    int32_t stackBudget;              // pending-entry budget of node_step's stack rule (kStackBudget; tests lower it to exercise resume entries)
     uint32_t nodeQuorum;              // leave the inner-node loop when fewer lanes than this are still in it (0 = never)
 };
 
@@ -112,13 +113,24 @@ RT_DEV void order_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
     const float k0 = sw ? kb : ka, k1 = sw ? ka : kb; const int32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
+// Stack rule: the siblings that are not visited next are pushed one by one (far-to-near) while
+//     pending entries + 2 + levels(node) <= budget            (budget = kStackBudget; a test knob can lower it to the level count),
+// otherwise ONE "resume" entry (node index and the set of hit slots still to visit) is pushed and the node is fetched and
+// tested again when that entry is popped (then against a cut that can only have shrunk).  In resume mode a level costs one
+// entry, so by induction pending + levels(node) <= kStackBudget holds at every visit and the 32-entry LDS stack cannot
+// overflow for any tree of <= kStackBudget levels (bvh_build.cpp) — without bounding how wide the nodes may be.
+constexpr int32_t kResumeBase = 0x40000000;     // references >= this: resume entry, (ref - base) = node << 4 | slot mask
+constexpr int kStackBudget = kStackDepth - 1;   // one entry is the exit sentinel
 // returns the next reference to visit (a child, or the popped stack top when no child is hit)
-RT_DEV int32_t node_step(const float4* nodes, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, bool counting) {
-    const float4* n = nodes + (size_t)cur * 4;
+RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, bool counting) {
+    const bool resumed = cur >= kResumeBase;
+    const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
+    const float4* n = nodes + (size_t)node * 4;
     const float4 q0 = n[0], q1 = n[1], q2 = n[2];
     const float2 q3 = *reinterpret_cast<const float2*>(n + 3);
-    const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = ex >> 24;
-    if (counting) nBox += cnt;
+    const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u, levels = ex >> 27;
+    const uint32_t valid = (resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u);
+    if (counting) nBox += (uint32_t)__popc(valid);
     const float Ax = __int_as_float((int)((ex & 0xFFu) << 23)) * r.ix, Ay = __int_as_float((int)(((ex >> 8) & 0xFFu) << 23)) * r.iy,
                 Az = __int_as_float((int)(((ex >> 16) & 0xFFu) << 23)) * r.iz;
     const float Bx = (q0.x - r.ox) * r.ix, By = (q0.y - r.oy) * r.iy, Bz = (q0.z - r.oz) * r.iz;
@@ -135,15 +147,22 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t cur, const RayPk& r, float
                  __builtin_elementwise_fma(v2f{ubyte_f(lz, 2), ubyte_f(lz, 3)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(hz, 2), ubyte_f(hz, 3)}, Az2, Bz2),
                  cut, k2, f2, k3, f3_);
     const float kMissKey = __builtin_inff();
-    k0 = (k0 <= f0) ? k0 : kMissKey;                                  // slots 0 and 1 are always valid (count >= 2)
-    k1 = (k1 <= f1) ? k1 : kMissKey;
-    k2 = (k2 <= f2 && cnt > 2u) ? k2 : kMissKey;
-    k3 = (k3 <= f3_ && cnt > 3u) ? k3 : kMissKey;
+    k0 = (k0 <= f0 && (valid & 1u)) ? k0 : kMissKey;
+    k1 = (k1 <= f1 && (valid & 2u)) ? k1 : kMissKey;
+    k2 = (k2 <= f2 && (valid & 4u)) ? k2 : kMissKey;
+    k3 = (k3 <= f3_ && (valid & 8u)) ? k3 : kMissKey;
+    const float s0 = k0, s1 = k1, s2 = k2, s3 = k3;                   // keys by slot, before the sort
     int32_t r0 = __float_as_int(q1.x), r1 = __float_as_int(q1.y), r2 = __float_as_int(q1.z), r3 = __float_as_int(q1.w);
     order_pair(k0, r0, k1, r1); order_pair(k2, r2, k3, r3); order_pair(k0, r0, k2, r2); order_pair(k1, r1, k3, r3); order_pair(k1, r1, k2, r2);
-    if (k3 < kMissKey) st.push(r3);
-    if (k2 < kMissKey) st.push(r2);
-    if (k1 < kMissKey) st.push(r1);
+    if ((st.top - 1) + 2 + (int)levels <= budget) {
+        if (k3 < kMissKey) st.push(r3);
+        if (k2 < kMissKey) st.push(r2);
+        if (k1 < kMissKey) st.push(r1);
+    } else if (k1 < kMissKey) {                                      // two or more hits and no room to push them one by one
+        const uint32_t hit = (s0 < kMissKey ? 1u : 0u) | (s1 < kMissKey ? 2u : 0u) | (s2 < kMissKey ? 4u : 0u) | (s3 < kMissKey ? 8u : 0u);
+        const uint32_t nearest = (s0 == k0) ? 1u : (s1 == k0) ? 2u : (s2 == k0) ? 4u : 8u;   // the sort keeps slot order on ties
+        st.push(kResumeBase + (int32_t)(((uint32_t)node << 4) | (hit & ~nearest)));
+    }
     return (k0 < kMissKey) ? r0 : st.pop();
 }
 
@@ -164,7 +183,7 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     int32_t cur = sc.rootRef;
     while (true) {
         while (cur >= 0) {
-            cur = node_step(sc.nodes, cur, pk, closestInfl, st, nBox, counting);
+            cur = node_step(sc.nodes, sc.stackBudget, cur, pk, closestInfl, st, nBox, counting);
             // lanes that reached a leaf wait outside this loop; once only a few lanes are still walking inner nodes,
             // stop and let everybody test their leaves (keeps SIMD lanes busy; pure scheduling, results unchanged)
             if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
@@ -239,7 +258,7 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
     bool occluded = false;
     while (!occluded) {
         while (cur >= 0) {
-            cur = node_step(sc.nodes, cur, pk, cut, st, nBox, counting);
+            cur = node_step(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, counting);
             if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
         }
         if (cur >= 0) continue;
@@ -287,7 +306,7 @@ RT_DEV bool trace_visible(const DevScene& sc, f3 o, f3 d, float dist, float tol,
         int32_t cur = sc.rootRef;
         while (!blocked) {
             while (cur >= 0) {
-                cur = node_step(sc.nodes, cur, pk, cut, st, nBox, counting);
+                cur = node_step(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, counting);
                 if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
             }
             if (cur >= 0) continue;

@@ -9,14 +9,15 @@ namespace rth {
 
 // 64-byte 4-wide node = four 16-byte quads; the child boxes are quantised to 8 bits per plane on a power-of-two grid
 // anchored at the node's own box, so ONE node fetch (4 x global_load_dwordx4) decides up to four children:
-//   q0 = origin.x origin.y origin.z (ex | ey << 8 | ez << 16 | count << 24)     grid step on axis a = 2^(e_a - 127)
+//   q0 = origin.x origin.y origin.z (ex | ey << 8 | ez << 16 | meta << 24)      grid step on axis a = 2^(e_a - 127)
+//        meta = count | levels << 3: children 0..count-1 are valid (count 2..4); levels = wide levels of this subtree (1 = leaves below)
 //   q1 = child[0..3]
 //   q2 = qlo.x[0..3] qlo.y[0..3] qlo.z[0..3] qhi.x[0..3]                        one byte per child, child i = byte i
 //   q3 = qhi.y[0..3] qhi.z[0..3] pad pad
 // plane = origin_a + q * 2^(e_a - 127); lo planes are rounded down and hi planes up (with 1/16 step of slack), so the
-// quantised box always contains the exact child box.  Children 0..count-1 are valid, count in 2..4.
-// child >= 0: inner node index.  child < 0: leaf, ~child = (firstTri << 2) | (count - 1), count 1..4.
-struct Node { float origin[3]; uint8_t ex[3]; uint8_t count; int32_t child[4]; uint8_t qlo[3][4]; uint8_t qhi[3][4]; uint32_t pad[2]; };
+// quantised box always contains the exact child box.
+// child >= 0: inner node index (< 2^26).  child < 0: leaf, ~child = (firstTri << 2) | (count - 1), count 1..4.
+struct Node { float origin[3]; uint8_t ex[3]; uint8_t meta; int32_t child[4]; uint8_t qlo[3][4]; uint8_t qhi[3][4]; uint32_t pad[2]; };
 // 48-byte leaf triangle = three quads: v0.xyz e1.x | e1.yz e2.xy | e2.z tri pad pad  (e1 = v1 - v0, e2 = v2 - v0)
 struct Tri { float v0[3], e1[3], e2[3]; uint32_t tri, pad[2]; };
 static_assert(sizeof(Node) == 64 && sizeof(Tri) == 48, "layout");
@@ -26,7 +27,7 @@ struct SceneBVH {
     std::vector<Tri> tris;     // leaf order
     int32_t rootRef = 0;       // inner index or leaf code
     uint32_t maxDepth = 0;     // deepest leaf of the binary SAH tree the wide tree is collapsed from (root = depth 0)
-    uint32_t stackNeed = 0;    // worst-case number of pending stack entries of an ordered traversal (<= kStackBudget by construction)
+    uint32_t levels = 0;       // wide levels of the tree (<= kStackBudget, see node_step's stack rule)
     uint32_t binaryNodes = 0;  // inner nodes of the binary tree before the collapse
 };
 

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
         while (true) {
             // inner nodes
             while (active && r.cur >= 0) {
-                { Stack st; st.lds = lds; st.top = r.top; r.cur = node_step(sc.nodes, r.cur, r.pk, r.cut, st, r.nBox, counting); r.top = st.top; }
+                { Stack st; st.lds = lds; st.top = r.top; r.cur = node_step(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, counting); r.top = st.top; }
                 if ((uint32_t)__popcll(__ballot(r.cur >= 0)) < sc.nodeQuorum) break;
             }
             // leaves

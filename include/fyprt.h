@@ -244,7 +244,10 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
  * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
  *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).
- * key 7: the same for every other kernel (default 0: measured neutral or slightly negative there). */
+ * key 7: the same for every other kernel (default 0: measured neutral or slightly negative there).
+ * key 8: pending-entry budget of the traversal stack rule (default and maximum 31, clamped from below to the tree's level
+ *        count): siblings are pushed one by one while pending + 2 + levels(node) <= budget, else as one resume entry.
+ *        Unlike keys 0-7 a lower value changes the visiting order (exact-t ties may resolve differently); for tests. */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 
 /* Library / build identification ("fyprt <version> gfx950 ..."). */

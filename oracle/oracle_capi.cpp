@@ -87,6 +87,9 @@ void orc_set_product_bvh(orc_handle* h, const void* nodes, uint32_t nodeCount, c
     p.rootRef = rootRef;
     bind(h, true);
 }
+// deepest traversal stack the product-order restatement has used so far, and a knob to force its resume-entry path
+int orc_product_max_stack(orc_handle* h) { return h->prodTracer->maxTop; }
+void orc_set_product_stack_budget(orc_handle* h, int budget) { h->prodTracer->stackBudget = budget; }
 void orc_set_camera(orc_handle* h, const orc_camera_desc* c) {
     Camera cam;
     cam.projection = mat4_from(c->projection); cam.view = mat4_from(c->view);

@@ -21,7 +21,7 @@
 
 namespace orc {
 
-struct PNode { float origin[3]; uint8_t ex[3], count; int32_t child[4]; uint8_t qlo[3][4], qhi[3][4]; uint32_t pad[2]; };
+struct PNode { float origin[3]; uint8_t ex[3], meta; int32_t child[4]; uint8_t qlo[3][4], qhi[3][4]; uint32_t pad[2]; };
 struct PTri { float v0[3], e1[3], e2[3]; uint32_t tri, pad[2]; };
 static_assert(sizeof(PNode) == 64 && sizeof(PTri) == 48, "layout");
 
@@ -30,29 +30,47 @@ struct ProductTracer : Tracer {
     explicit ProductTracer(const Scene& s) : sc(s) {}
     static inline float safeInv(float d) { return 1.0f / ((fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d); }
     static inline float pow2e(uint8_t e) { uint32_t b = (uint32_t)e << 23; float f; memcpy(&f, &b, 4); return f; }
-    // one node visit: pushes the hit children far-to-near, returns true and the nearest in `next` if any child is hit
-    bool Visit(const PNode& n, float ox, float oy, float oz, float ix, float iy, float iz, float cut, int32_t* stack, int& top, int32_t& next, Counters& c) const {
-        c.boxTests += n.count;
+    // one node visit (`cur` is a node index or a resume entry): pushes the hit children that are not visited next — one by
+    // one, far-to-near, while pending + 2 + levels(node) <= 31, else as ONE resume entry (node << 4 | remaining hit slots) —
+    // and returns true and the nearest hit child in `next` if any child is hit.
+    static constexpr int32_t kResumeBase = 0x40000000;
+    bool Visit(int32_t cur, float ox, float oy, float oz, float ix, float iy, float iz, float cut, int32_t* stack, int& top, int32_t& next, Counters& c) const {
+        const bool resumed = cur >= kResumeBase;
+        const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
+        const PNode& n = nodes[node];
+        const uint32_t cnt = n.meta & 7u, levels = n.meta >> 3;
+        const uint32_t valid = (resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u);
+        c.boxTests += (uint64_t)__builtin_popcount(valid);
         const float o[3] = {ox, oy, oz}, inv[3] = {ix, iy, iz};
         float A[3], B[3];
         for (int a = 0; a < 3; ++a) { A[a] = pow2e(n.ex[a]) * inv[a]; B[a] = (n.origin[a] - o[a]) * inv[a]; }
-        float key[4]; int32_t ref[4];
+        float key[4], slotKey[4]; int32_t ref[4];
         for (int i = 0; i < 4; ++i) {
             float lo[3], hi[3];
             for (int a = 0; a < 3; ++a) { lo[a] = fmaf((float)n.qlo[a][i], A[a], B[a]); hi[a] = fmaf((float)n.qhi[a][i], A[a], B[a]); }
             float tnear = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), 0.0f));
             float tfar = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fminf(fmaxf(lo[2], hi[2]), cut));
-            key[i] = (tnear <= tfar && i < (int)n.count) ? tnear : INFINITY;
+            key[i] = slotKey[i] = (tnear <= tfar && ((valid >> i) & 1u)) ? tnear : INFINITY;
             ref[i] = n.child[i];
         }
         auto order = [&](int a, int b) { if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(ref[a], ref[b]); } };
         order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
-        if (key[3] < INFINITY) stack[top++] = ref[3];
-        if (key[2] < INFINITY) stack[top++] = ref[2];
-        if (key[1] < INFINITY) stack[top++] = ref[1];
+        if (top + 2 + (int)levels <= stackBudget) {
+            if (key[3] < INFINITY) stack[top++] = ref[3];
+            if (key[2] < INFINITY) stack[top++] = ref[2];
+            if (key[1] < INFINITY) stack[top++] = ref[1];
+        } else if (key[1] < INFINITY) {
+            uint32_t hit = 0, nearest = 8;
+            for (int i = 0; i < 4; ++i) if (slotKey[i] < INFINITY) hit |= 1u << i;
+            for (int i = 0; i < 4; ++i) if (slotKey[i] == key[0]) { nearest = 1u << i; break; }
+            stack[top++] = kResumeBase + (int32_t)(((uint32_t)node << 4) | (hit & ~nearest));
+        }
+        maxTop = top > maxTop ? top : maxTop;
         if (key[0] < INFINITY) { next = ref[0]; return true; }
         return false;
     }
+    int stackBudget = 31;       // the product's tuning key 8
+    mutable int maxTop = 0;     // deepest stack seen (diagnostic; racy across OpenMP threads, only ever compared with 31)
     Payload Trace(const Ray& ray, Counters& c) const override {
         c.rays++;
         if (tris.empty()) return Miss();
@@ -62,7 +80,7 @@ struct ProductTracer : Tracer {
         int32_t stack[128]; int top = 0; int32_t cur = rootRef;
         while (true) {
             if (cur >= 0) {
-                if (Visit(nodes[cur], ox, oy, oz, ix, iy, iz, closestInfl, stack, top, cur, c)) continue;
+                if (Visit(cur, ox, oy, oz, ix, iy, iz, closestInfl, stack, top, cur, c)) continue;
             } else {
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -115,7 +133,7 @@ struct ProductTracer : Tracer {
         Payload r = Miss(); r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
         while (true) {
             if (cur >= 0) {
-                if (Visit(nodes[cur], ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
+                if (Visit(cur, ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
             } else {
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -152,7 +170,7 @@ struct ProductTracer : Tracer {
             int32_t stack[128]; int top = 0; int32_t cur = rootRef;
             while (true) {
                 if (cur >= 0) {
-                    if (Visit(nodes[cur], ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
+                    if (Visit(cur, ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
                 } else {
                     uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                     for (uint32_t k = 0; k < cnt; ++k) {

@@ -111,6 +111,12 @@ class Oracle:
         n, t = np.ascontiguousarray(bvh["nodes"]), np.ascontiguousarray(bvh["tris"])
         self.lib.orc_set_product_bvh(self.h, n.ctypes.data, len(n), t.ctypes.data, len(t), int(bvh["root"]))
 
+    def product_max_stack(self):
+        return int(self.lib.orc_product_max_stack(self.h))
+
+    def set_product_stack_budget(self, budget):
+        self.lib.orc_set_product_stack_budget(self.h, int(budget))
+
     def use_reference_tracer(self):
         self.lib.orc_use_reference_tracer(self.h)
 

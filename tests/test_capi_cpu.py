@@ -75,7 +75,7 @@ def test_bvh_invariants(name):
     b = ctx.export_bvh()
     nodes, tris = b["nodes"], b["tris"]
     assert sorted(tris["tri"].tolist()) == list(range(len(sc.triangles)))   # every triangle exactly once
-    assert b["max_stack"] + 1 <= 32                                          # fits the 32-entry LDS traversal stack (one entry = exit sentinel)
+    assert b["max_stack"] <= 31                                              # wide levels: what node_step's stack rule needs (<= 31)
     pos = sc.world_vertices["position"]
     t = sc.triangles
     # leaf records are (v0, v1 - v0, v2 - v0) of the original triangle, bit for bit
@@ -87,14 +87,14 @@ def test_bvh_invariants(name):
     tri_lo = np.minimum(np.minimum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
     tri_hi = np.maximum(np.maximum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
     seen = np.zeros(len(nodes), dtype=int)
-    assert ((nodes["count"] >= 2) & (nodes["count"] <= 4)).all()
+    assert (((nodes["meta"] & 7) >= 2) & ((nodes["meta"] & 7) <= 4)).all() and len(nodes) < (1 << 26)
 
     def bounds(ref):
-        """-> (lo, hi, stack need) of the subtree; checks that every quantised child box contains everything below it."""
+        """-> (lo, hi, wide levels) of the subtree; checks that every quantised child box contains everything below it."""
         if ref >= 0:
             seen[ref] += 1
             n = nodes[ref]
-            k = int(n["count"])
+            k = int(n["meta"]) & 7
             step = np.ldexp(np.float32(1.0), n["ex"].astype(np.int32) - 127).astype(np.float32)
             lo_all, hi_all, need = [], [], 0
             for i in range(k):
@@ -104,7 +104,8 @@ def test_bvh_invariants(name):
                 assert (qlo <= l).all() and (qhi >= h).all()
                 lo_all.append(l); hi_all.append(h); need = max(need, cn)
             assert (n["origin"] == np.min(lo_all, axis=0)).all()                                      # grid anchored at the node's own box
-            return np.min(lo_all, axis=0), np.max(hi_all, axis=0), (k - 1) + need
+            assert int(n["meta"]) >> 3 == 1 + need                                                    # recorded level count
+            return np.min(lo_all, axis=0), np.max(hi_all, axis=0), 1 + need
         code = ~ref
         first, cnt = code >> 2, (code & 3) + 1
         ids = tris["tri"][first:first + cnt]
@@ -115,6 +116,7 @@ def test_bvh_invariants(name):
     _, _, need = bounds(b["root"])
     assert (seen == 1).all()
     assert need == b["max_stack"] <= 31
+    assert (nodes["meta"] & 7).mean() > 3.0                                  # the collapse really is wide
     ctx.close()
 
 
@@ -138,7 +140,7 @@ def test_bvh_depth_is_bounded_by_construction():
     ctx = capi.Context(-1)
     ctx.upload_scene(sc)
     b = ctx.export_bvh()
-    assert b["max_stack"] + 1 <= 32
+    assert b["max_stack"] <= 31
     assert sorted(b["tris"]["tri"].tolist()) == list(range(n))
     ctx.close()
 

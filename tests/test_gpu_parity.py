@@ -125,3 +125,33 @@ def test_errors_and_state(gpu):
     with pytest.raises(capi.FyprtError):
         ctx.set_rows(10, 5)
     ctx.close()
+
+
+@pytest.mark.parametrize("tech", [capi.BRUTE_FORCE, capi.NEE, capi.RESTIR_DI, capi.RESTIR_GI])
+def test_bit_exact_with_resume_entries(gpu, oracle_built, tech):
+    """Tuning key 8 lowered to the tree's level count: traversal keeps one pending stack entry per level (resume entries,
+    rt_device.h node_step) instead of pushing siblings one by one.  Same bar: every buffer bit-exact against the oracle's
+    restatement running with the same budget, and the oracle's stack never exceeds it."""
+    from oraclelib import Oracle
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 160, 96
+    cam = mk_cam(W, H)
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.upload_scene(sc)
+    ctx.set_camera(cam)
+    ctx.set_tuning(8, 0)                                   # clamped from below to the level count
+    bvh = ctx.export_bvh()
+    orc = Oracle(sc, W, H)
+    orc.set_camera(cam)
+    orc.use_product_bvh(bvh)
+    orc.set_product_stack_budget(bvh["max_stack"])
+    st = settings_for(tech)
+    for f in range(2):
+        st.rand_seed = 1 + f
+        ctx.render(st)
+        orc.render(st)
+    img_g, acc_g = ctx.readback()
+    assert bits_equal(acc_g, orc.accum()).all() and (img_g == orc.image()).all()
+    assert orc.product_max_stack() <= bvh["max_stack"]
+    ctx.close()

@@ -10,8 +10,11 @@ from fypraytracer_amd import capi, scenes
 from oraclelib import Oracle
 
 
+@pytest.mark.parametrize("tight_stack", [False, True])
 @pytest.mark.parametrize("name,min_same", [("hall_small", 0.9995), ("cornell", 0.99)])
-def test_random_rays_same_closest_hit(oracle_built, name, min_same):
+def test_random_rays_same_closest_hit(oracle_built, name, min_same, tight_stack):
+    """tight_stack: the stack rule's budget is lowered to the tree's level count, so nearly every multi-hit visit goes
+    through a resume entry (one pending entry per level) instead of pushing the siblings one by one."""
     sc = scenes.cornell_box() if name == "cornell" else scenes.hall_scene_small()
     ctx = capi.Context(-1)
     ctx.upload_scene(sc)
@@ -30,6 +33,8 @@ def test_random_rays_same_closest_hit(oracle_built, name, min_same):
     for i in range(n):
         ref[i], _ = o.trace(origins[i], dirs[i])
     o.use_product_bvh(bvh)
+    if tight_stack:
+        o.set_product_stack_budget(bvh["max_stack"])
     got = np.zeros(n, dtype=capi.PAYLOAD_DTYPE)
     box = tri = 0
     for i in range(n):
@@ -41,7 +46,8 @@ def test_random_rays_same_closest_hit(oracle_built, name, min_same):
     d = ~same
     assert np.allclose(ref["hitDistance"][d], got["hitDistance"][d], rtol=1e-6)
     assert (ref["hitDistance"] > 0).mean() > 0.8                      # (the Cornell box is open at the front)
-    assert box / n < 200 and tri / n < 20                             # ordered + culled traversal stays cheap
+    assert box / n < (400 if tight_stack else 200) and tri / n < 20   # ordered + culled traversal stays cheap
+    assert o.product_max_stack() <= (bvh["max_stack"] if tight_stack else 31)   # pending entries never exceed the budget
     ctx.close()
 
 
