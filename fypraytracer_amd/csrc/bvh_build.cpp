@@ -153,6 +153,7 @@ struct Collapser {
     static void quantise(Node& n, const Child* ch, int k) {
         Box nb; for (int i = 0; i < k; ++i) nb.grow(ch[i].b);
         std::memset(&n, 0, sizeof n);
+        for (int a = 0; a < 3; ++a) for (int i = k; i < 4; ++i) { n.qlo[a][i] = 255; n.qhi[a][i] = 0; }   // unused slots: an inverted box no ray can hit (node_step)
         n.meta = (uint8_t)k;
         for (int a = 0; a < 3; ++a) {
             const float lo = nb.lo[a]; n.origin[a] = lo;

@@ -102,11 +102,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct RayPk { float ox, oy, oz, ix, iy, iz; };
 RT_DEV RayPk make_raypk(f3 o, float ix, float iy, float iz) { RayPk r; r.ox = o.x; r.oy = o.y; r.oz = o.z; r.ix = ix; r.iy = iy; r.iz = iz; return r; }
 RT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); }
-RT_DEV void slab_of_pair(v2f lx, v2f hx, v2f ly, v2f hy, v2f lz, v2f hz, float cut, float& n0, float& f0, float& n1, float& f1) {
-    n0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx.x, hx.x), __builtin_fminf(ly.x, hy.x)), __builtin_fmaxf(__builtin_fminf(lz.x, hz.x), 0.0f));
-    f0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx.x, hx.x), __builtin_fmaxf(ly.x, hy.x)), __builtin_fminf(__builtin_fmaxf(lz.x, hz.x), cut));
-    n1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx.y, hx.y), __builtin_fminf(ly.y, hy.y)), __builtin_fmaxf(__builtin_fminf(lz.y, hz.y), 0.0f));
-    f1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx.y, hx.y), __builtin_fmaxf(ly.y, hy.y)), __builtin_fminf(__builtin_fmaxf(lz.y, hz.y), cut));
+// entry / exit parameter of two children (x = first, y = second of the pair) from their near / far plane parameters
+RT_DEV void slab_of_pair(v2f nx, v2f fx, v2f ny, v2f fy, v2f nz, v2f fz, float cut, float& n0, float& f0, float& n1, float& f1) {
+    n0 = __builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), __builtin_fmaxf(nz.x, 0.0f));
+    f0 = __builtin_fminf(__builtin_fminf(fx.x, fy.x), __builtin_fminf(fz.x, cut));
+    n1 = __builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), __builtin_fmaxf(nz.y, 0.0f));
+    f1 = __builtin_fminf(__builtin_fminf(fx.y, fy.y), __builtin_fminf(fz.y, cut));
 }
 RT_DEV void order_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
     const bool sw = kb < ka;
@@ -129,28 +130,36 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     const float4 q0 = n[0], q1 = n[1], q2 = n[2];
     const float2 q3 = *reinterpret_cast<const float2*>(n + 3);
     const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u, levels = ex >> 27;
-    const uint32_t valid = (resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u);
-    if (counting) nBox += (uint32_t)__popc(valid);
+    if (counting) nBox += (uint32_t)__popc((resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u));
     const float Ax = __int_as_float((int)((ex & 0xFFu) << 23)) * r.ix, Ay = __int_as_float((int)(((ex >> 8) & 0xFFu) << 23)) * r.iy,
                 Az = __int_as_float((int)(((ex >> 16) & 0xFFu) << 23)) * r.iz;
     const float Bx = (q0.x - r.ox) * r.ix, By = (q0.y - r.oy) * r.iy, Bz = (q0.z - r.oz) * r.iz;
     const v2f Ax2 = v2f{Ax, Ax}, Ay2 = v2f{Ay, Ay}, Az2 = v2f{Az, Az}, Bx2 = v2f{Bx, Bx}, By2 = v2f{By, By}, Bz2 = v2f{Bz, Bz};
     const uint32_t lx = (uint32_t)__float_as_int(q2.x), ly = (uint32_t)__float_as_int(q2.y), lz = (uint32_t)__float_as_int(q2.z),
                    hx = (uint32_t)__float_as_int(q2.w), hy = (uint32_t)__float_as_int(q3.x), hz = (uint32_t)__float_as_int(q3.y);
+    // the ray enters a slab through the lo plane where it travels in +axis direction and through the hi plane otherwise:
+    // select the four children's near / far plane bytes with one v_cndmask per axis and side instead of a min and a max per
+    // plane pair.  Unused child slots hold lo = 255, hi = 0 on every axis, which this test can never hit.
+    const bool bx = r.ix < 0.0f, by = r.iy < 0.0f, bz = r.iz < 0.0f;
+    const uint32_t nxq = bx ? hx : lx, fxq = bx ? lx : hx, nyq = by ? hy : ly, fyq = by ? ly : hy, nzq = bz ? hz : lz, fzq = bz ? lz : hz;
     float k0, k1, k2, k3, f0, f1, f2, f3_;
-    slab_of_pair(__builtin_elementwise_fma(v2f{ubyte_f(lx, 0), ubyte_f(lx, 1)}, Ax2, Bx2), __builtin_elementwise_fma(v2f{ubyte_f(hx, 0), ubyte_f(hx, 1)}, Ax2, Bx2),
-                 __builtin_elementwise_fma(v2f{ubyte_f(ly, 0), ubyte_f(ly, 1)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(hy, 0), ubyte_f(hy, 1)}, Ay2, By2),
-                 __builtin_elementwise_fma(v2f{ubyte_f(lz, 0), ubyte_f(lz, 1)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(hz, 0), ubyte_f(hz, 1)}, Az2, Bz2),
+    slab_of_pair(__builtin_elementwise_fma(v2f{ubyte_f(nxq, 0), ubyte_f(nxq, 1)}, Ax2, Bx2), __builtin_elementwise_fma(v2f{ubyte_f(fxq, 0), ubyte_f(fxq, 1)}, Ax2, Bx2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(nyq, 0), ubyte_f(nyq, 1)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(fyq, 0), ubyte_f(fyq, 1)}, Ay2, By2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(nzq, 0), ubyte_f(nzq, 1)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(fzq, 0), ubyte_f(fzq, 1)}, Az2, Bz2),
                  cut, k0, f0, k1, f1);
-    slab_of_pair(__builtin_elementwise_fma(v2f{ubyte_f(lx, 2), ubyte_f(lx, 3)}, Ax2, Bx2), __builtin_elementwise_fma(v2f{ubyte_f(hx, 2), ubyte_f(hx, 3)}, Ax2, Bx2),
-                 __builtin_elementwise_fma(v2f{ubyte_f(ly, 2), ubyte_f(ly, 3)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(hy, 2), ubyte_f(hy, 3)}, Ay2, By2),
-                 __builtin_elementwise_fma(v2f{ubyte_f(lz, 2), ubyte_f(lz, 3)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(hz, 2), ubyte_f(hz, 3)}, Az2, Bz2),
+    slab_of_pair(__builtin_elementwise_fma(v2f{ubyte_f(nxq, 2), ubyte_f(nxq, 3)}, Ax2, Bx2), __builtin_elementwise_fma(v2f{ubyte_f(fxq, 2), ubyte_f(fxq, 3)}, Ax2, Bx2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(nyq, 2), ubyte_f(nyq, 3)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(fyq, 2), ubyte_f(fyq, 3)}, Ay2, By2),
+                 __builtin_elementwise_fma(v2f{ubyte_f(nzq, 2), ubyte_f(nzq, 3)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(fzq, 2), ubyte_f(fzq, 3)}, Az2, Bz2),
                  cut, k2, f2, k3, f3_);
     const float kMissKey = __builtin_inff();
-    k0 = (k0 <= f0 && (valid & 1u)) ? k0 : kMissKey;
-    k1 = (k1 <= f1 && (valid & 2u)) ? k1 : kMissKey;
-    k2 = (k2 <= f2 && (valid & 4u)) ? k2 : kMissKey;
-    k3 = (k3 <= f3_ && (valid & 8u)) ? k3 : kMissKey;
+    k0 = (k0 <= f0) ? k0 : kMissKey;
+    k1 = (k1 <= f1) ? k1 : kMissKey;
+    k2 = (k2 <= f2) ? k2 : kMissKey;
+    k3 = (k3 <= f3_) ? k3 : kMissKey;
+    if (__ballot(resumed) != 0ull) {                                  // rare: a resumed visit only looks at the slots still owed
+        const uint32_t allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu;
+        k0 = (allow & 1u) ? k0 : kMissKey; k1 = (allow & 2u) ? k1 : kMissKey; k2 = (allow & 4u) ? k2 : kMissKey; k3 = (allow & 8u) ? k3 : kMissKey;
+    }
     const float s0 = k0, s1 = k1, s2 = k2, s3 = k3;                   // keys by slot, before the sort
     int32_t r0 = __float_as_int(q1.x), r1 = __float_as_int(q1.y), r2 = __float_as_int(q1.z), r3 = __float_as_int(q1.w);
     order_pair(k0, r0, k1, r1); order_pair(k2, r2, k3, r3); order_pair(k0, r0, k2, r2); order_pair(k1, r1, k3, r3); order_pair(k1, r1, k2, r2);
@@ -166,6 +175,12 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     return (k0 < kMissKey) ? r0 : st.pop();
 }
 
+// A ray with a NaN or infinite component can hit no triangle (every Möller–Trumbore comparison fails), but its slab tests
+// would pass everywhere: such rays are answered as misses up front instead of walking the whole tree.
+RT_DEV bool ray_not_finite(f3 o, f3 d) {
+    const float z = ((o.x - o.x) + (o.y - o.y)) + ((o.z - o.z) + (d.x - d.x)) + ((d.y - d.y) + (d.z - d.z));
+    return !(z == 0.0f);
+}
 RT_DEV float safe_inv(float d) { return 1.0f / ((__builtin_fabsf(d) < 1e-30f) ? __builtin_copysignf(1e-30f, d) : d); }
 
 // Closest hit over the two-level BVH.  Ordered traversal (near child first, far child pushed),
@@ -176,7 +191,7 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     Hit h; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.tri = -1;
     const bool counting = sc.rayCounter != nullptr;        // wave-uniform (kernel argument)
     uint32_t nBox = 0, nTri = 0;
-    if (sc.triCount == 0) { if (counting) atomicAdd(sc.rayCounter, 1ull); return h; }
+    if (sc.triCount == 0 || ray_not_finite(o, d)) { if (counting) atomicAdd(sc.rayCounter, 1ull); return h; }
     const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     float closestInfl = h.t * 1.000001f;
     Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
@@ -299,7 +314,7 @@ RT_DEV bool trace_visible(const DevScene& sc, f3 o, f3 d, float dist, float tol,
     const bool counting = sc.rayCounter != nullptr;
     uint32_t nBox = 0, nTri = 0;
     bool found = false, blocked = false;
-    if (sc.triCount != 0) {
+    if (sc.triCount != 0 && !ray_not_finite(o, d)) {
         const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
         const float tLo = dist - tol, tHi = dist + tol, cut = tHi * 1.000001f;
         Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);

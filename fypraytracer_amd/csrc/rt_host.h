@@ -15,7 +15,7 @@ namespace rth {
 //   q2 = qlo.x[0..3] qlo.y[0..3] qlo.z[0..3] qhi.x[0..3]                        one byte per child, child i = byte i
 //   q3 = qhi.y[0..3] qhi.z[0..3] pad pad
 // plane = origin_a + q * 2^(e_a - 127); lo planes are rounded down and hi planes up (with 1/16 step of slack), so the
-// quantised box always contains the exact child box.
+// quantised box always contains the exact child box.  Unused slots hold qlo = 255, qhi = 0 on every axis.
 // child >= 0: inner node index (< 2^26).  child < 0: leaf, ~child = (firstTri << 2) | (count - 1), count 1..4.
 struct Node { float origin[3]; uint8_t ex[3]; uint8_t meta; int32_t child[4]; uint8_t qlo[3][4]; uint8_t qhi[3][4]; uint32_t pad[2]; };
 // 48-byte leaf triangle = three quads: v0.xyz e1.x | e1.yz e2.xy | e2.z tri pad pad  (e1 = v1 - v0, e2 = v2 - v0)

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 r.hitTri = r.closestMode ? -1 : (int32_t)r.lightTri;
                 r.nBox = 0; r.nTri = 1;
                 r.top = 0; lane_push(lds, r.top, kExit);
-                r.cur = (sc.triCount == 0) ? kExit : sc.rootRef;
+                r.cur = (sc.triCount == 0 || ray_not_finite(r.o, r.d)) ? kExit : sc.rootRef;   // (a non-finite ray also fails the light test above: closest mode, miss)
                 active = true;
             }
         }

@@ -12,7 +12,8 @@
 //   child >= 0 : inner node index;  child < 0 : leaf, ~child = (firstTri << 2) | (count-1)
 //   tri   (48 B): float v0[3], e1[3], e2[3]; uint32 triangleIndex; uint32 pad[2]
 // Traversal: per visit A_a = 2^(ex_a-127) * (1/d_a), B_a = (origin_a - o_a) * (1/d_a), slab parameter of a plane
-// t = fma(q, A_a, B_a); children culled against cut (= closest*1.000001f, or the light / visibility distance); hit
+// t = fma(q, A_a, B_a), entry plane = lo where 1/d_a >= 0 else hi (unused slots hold lo 255 / hi 0 and never pass);
+// children culled against cut (= closest*1.000001f, or the light / visibility distance); hit
 // children ordered by entry distance with the 5-comparator network (0,1)(2,3)(0,2)(1,3)(1,2), strict "<" so ties keep
 // slot order; nearest visited next, the others pushed far-to-near; |d| < 1e-30 replaced by copysign(1e-30, d);
 // Möller–Trumbore identical to Renderer.cu:513-537 on (v0, e1, e2).
@@ -29,6 +30,12 @@ struct ProductTracer : Tracer {
     const Scene& sc; std::vector<PNode> nodes; std::vector<PTri> tris; int32_t rootRef = 0;
     explicit ProductTracer(const Scene& s) : sc(s) {}
     static inline float safeInv(float d) { return 1.0f / ((fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d); }
+    // non-finite rays are answered as misses up front (the product's ray_not_finite; no triangle test can pass for them)
+    static inline bool notFinite(const Ray& r) {
+        const vec3 &o = r.origin, &d = r.direction;
+        const float z = ((o.x - o.x) + (o.y - o.y)) + ((o.z - o.z) + (d.x - d.x)) + ((d.y - d.y) + (d.z - d.z));
+        return !(z == 0.0f);
+    }
     static inline float pow2e(uint8_t e) { uint32_t b = (uint32_t)e << 23; float f; memcpy(&f, &b, 4); return f; }
     // one node visit (`cur` is a node index or a resume entry): pushes the hit children that are not visited next — one by
     // one, far-to-near, while pending + 2 + levels(node) <= 31, else as ONE resume entry (node << 4 | remaining hit slots) —
@@ -39,18 +46,22 @@ struct ProductTracer : Tracer {
         const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
         const PNode& n = nodes[node];
         const uint32_t cnt = n.meta & 7u, levels = n.meta >> 3;
-        const uint32_t valid = (resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u);
-        c.boxTests += (uint64_t)__builtin_popcount(valid);
+        const uint32_t allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu;
+        c.boxTests += (uint64_t)__builtin_popcount(allow & ((1u << cnt) - 1u));
         const float o[3] = {ox, oy, oz}, inv[3] = {ix, iy, iz};
         float A[3], B[3];
         for (int a = 0; a < 3; ++a) { A[a] = pow2e(n.ex[a]) * inv[a]; B[a] = (n.origin[a] - o[a]) * inv[a]; }
         float key[4], slotKey[4]; int32_t ref[4];
         for (int i = 0; i < 4; ++i) {
-            float lo[3], hi[3];
-            for (int a = 0; a < 3; ++a) { lo[a] = fmaf((float)n.qlo[a][i], A[a], B[a]); hi[a] = fmaf((float)n.qhi[a][i], A[a], B[a]); }
-            float tnear = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), 0.0f));
-            float tfar = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fminf(fmaxf(lo[2], hi[2]), cut));
-            key[i] = slotKey[i] = (tnear <= tfar && ((valid >> i) & 1u)) ? tnear : INFINITY;
+            float tn[3], tf[3];       // entry through the lo plane where the ray travels in +axis direction, else through the hi plane
+            for (int a = 0; a < 3; ++a) {
+                const bool neg = inv[a] < 0.0f;
+                tn[a] = fmaf((float)(neg ? n.qhi[a][i] : n.qlo[a][i]), A[a], B[a]);
+                tf[a] = fmaf((float)(neg ? n.qlo[a][i] : n.qhi[a][i]), A[a], B[a]);
+            }
+            float tnear = fmaxf(fmaxf(tn[0], tn[1]), fmaxf(tn[2], 0.0f));
+            float tfar = fminf(fminf(tf[0], tf[1]), fminf(tf[2], cut));
+            key[i] = slotKey[i] = (tnear <= tfar && ((allow >> i) & 1u)) ? tnear : INFINITY;   // unused slots (lo 255, hi 0) never pass
             ref[i] = n.child[i];
         }
         auto order = [&](int a, int b) { if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(ref[a], ref[b]); } };
@@ -73,7 +84,7 @@ struct ProductTracer : Tracer {
     mutable int maxTop = 0;     // deepest stack seen (diagnostic; racy across OpenMP threads, only ever compared with 31)
     Payload Trace(const Ray& ray, Counters& c) const override {
         c.rays++;
-        if (tris.empty()) return Miss();
+        if (tris.empty() || notFinite(ray)) return Miss();
         const float ox = ray.origin.x, oy = ray.origin.y, oz = ray.origin.z;
         const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
         float closest = FLT_MAX, closestInfl = closest * 1.000001f; int closestTri = -1; float cu = 0.0f, cv = 0.0f;
@@ -82,6 +93,7 @@ struct ProductTracer : Tracer {
             if (cur >= 0) {
                 if (Visit(cur, ox, oy, oz, ix, iy, iz, closestInfl, stack, top, cur, c)) continue;
             } else {
+                if (cur == INT32_MIN) break;                       // the product's exit sentinel (an unused child slot holds it)
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const PTri& T = tris[first + k];
@@ -135,6 +147,7 @@ struct ProductTracer : Tracer {
             if (cur >= 0) {
                 if (Visit(cur, ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
             } else {
+                if (cur == INT32_MIN) break;                       // the product's exit sentinel (an unused child slot holds it)
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const PTri& T = tris[first + k];
@@ -163,7 +176,7 @@ struct ProductTracer : Tracer {
     bool TraceVisible(const Ray& ray, float dist, float tol, Counters& c) const override {
         c.rays++;
         bool found = false;
-        if (!tris.empty()) {
+        if (!tris.empty() && !notFinite(ray)) {
             const float ox = ray.origin.x, oy = ray.origin.y, oz = ray.origin.z;
             const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
             const float tLo = dist - tol, tHi = dist + tol, cut = tHi * 1.000001f;
@@ -172,6 +185,7 @@ struct ProductTracer : Tracer {
                 if (cur >= 0) {
                     if (Visit(cur, ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
                 } else {
+                    if (cur == INT32_MIN) break;
                     uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
                     for (uint32_t k = 0; k < cnt; ++k) {
                         const PTri& T = tris[first + k];

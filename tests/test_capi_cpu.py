@@ -103,6 +103,7 @@ def test_bvh_invariants(name):
                 qhi = (n["origin"] + n["qhi"][:, i].astype(np.float32) * step).astype(np.float32)
                 assert (qlo <= l).all() and (qhi >= h).all()
                 lo_all.append(l); hi_all.append(h); need = max(need, cn)
+            assert (n["qlo"][:, k:] == 255).all() and (n["qhi"][:, k:] == 0).all()                       # unused slots: inverted box
             assert (n["origin"] == np.min(lo_all, axis=0)).all()                                      # grid anchored at the node's own box
             assert int(n["meta"]) >> 3 == 1 + need                                                    # recorded level count
             return np.min(lo_all, axis=0), np.max(hi_all, axis=0), 1 + need
