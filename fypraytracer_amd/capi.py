@@ -122,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_create", "fyprt_destroy", "fyprt_last_error", "fyprt_resize", "fyprt_set_rows", "fyprt_upload_scene",
     "fyprt_set_camera", "fyprt_render", "fyprt_render_async", "fyprt_synchronize", "fyprt_readback",
     "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer", "fyprt_frame_timings",
-    "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees",
+    "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees", "fyprt_get_tuning",
     "fyprt_set_ray_counting", "fyprt_set_tuning", "fyprt_version",
 ]
 
@@ -166,6 +166,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_reset_frame_index.argtypes = [vp]
     lib.fyprt_frame_index.argtypes = [vp]
     lib.fyprt_frame_index.restype = u32
+    lib.fyprt_get_tuning.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     lib.fyprt_export_bvh.argtypes = [vp, vp, C.POINTER(u32), vp, C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]
     lib.fyprt_export_lighttrees.argtypes = [vp, vp, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(u32), vp, vp, vp]
     lib.fyprt_set_ray_counting.argtypes = [vp, C.c_int]
@@ -332,13 +333,18 @@ class Context:
     def set_tuning(self, key: int, value: int):
         self._check(self.lib.fyprt_set_tuning(self.h, key, value))
 
+    def get_tuning(self, key: int) -> int:
+        v = C.c_int()
+        self._check(self.lib.fyprt_get_tuning(self.h, key, C.byref(v)))
+        return v.value
+
     def export_bvh(self):
         nn, nt, root, depth = C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_uint32()
         self._check(self.lib.fyprt_export_bvh(self.h, None, C.byref(nn), None, C.byref(nt), C.byref(root), C.byref(depth)))
         nodes = np.empty(nn.value, dtype=BVH_NODE_DTYPE)
         tris = np.empty(nt.value, dtype=BVH_TRI_DTYPE)
         self._check(self.lib.fyprt_export_bvh(self.h, _ptr(nodes), C.byref(nn), _ptr(tris), C.byref(nt), C.byref(root), C.byref(depth)))
-        return {"nodes": nodes, "tris": tris, "root": root.value, "max_stack": depth.value}
+        return {"nodes": nodes, "tris": tris, "root": root.value, "max_stack": depth.value, "stack_budget": self.get_tuning(8)}
 
     def export_lighttrees(self, mesh_count: int):
         tc, tr, bt = C.c_uint32(), C.c_uint32(), C.c_uint32()

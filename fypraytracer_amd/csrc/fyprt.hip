@@ -59,7 +59,8 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
-    int tuning[9] = {2, 1, 5, 0, 128, 24, 16, 0, 31};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
+    int tuning[9] = {2, 1, 0, 0, 128, 24, 32, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
@@ -73,6 +74,13 @@ struct fyprt_context {
 };
 
 #define HIPCHK(ctx, call) do { int _rc = (ctx)->hip((call), #call); if (_rc != FYPRT_OK) return _rc; } while (0)
+
+// Effective pending-entry budget of node_step's stack rule for the uploaded tree: tuning key 8 if set, else a few entries
+// above the tree's level count; never below the level count (the induction needs it), never above kStackBudget.
+static int effective_stack_budget(const fyprt_context* c) {
+    const int levels = (int)c->hostBvh.levels;
+    return std::min((int)rth::kStackBudget, std::max(levels, c->tuning[8] > 0 ? c->tuning[8] : std::max(levels + 8, 19)));
+}
 
 extern "C" {
 
@@ -339,7 +347,12 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
     c->dsc.nodeQuorum = (uint32_t)c->tuning[7];                 // 0 by default: measured best for every fused per-pixel kernel
-    c->dsc.stackBudget = std::min((int)rth::kStackBudget, std::max((int)c->hostBvh.levels, c->tuning[8]));   // never below the level count: node_step's induction
+    // traversal-stack budget (node_step's rule): never below the level count (the induction), never above the 31 the node
+    // format records; by default a few entries above the level count, so the LDS stack is no larger than this tree needs
+    // and more workgroups fit a CU (LDS is what limits residency: (budget + 1) KB per 256-thread workgroup)
+    const int budget = effective_stack_budget(c);
+    c->dsc.stackBudget = budget;
+    const size_t ldsBytes = (size_t)(budget + 1) * kBlock * sizeof(int32_t);
     if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
@@ -357,27 +370,27 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
     int launches = 0;
     switch (tech) {
-        case FYPRT_BRUTE_FORCE: hipLaunchKernelGGL(k_path<T_BRUTE>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_UNIFORM_SAMPLING: hipLaunchKernelGGL(k_path<T_UNIFORM>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_COSINE_WEIGHTED_SAMPLING: hipLaunchKernelGGL(k_path<T_COSINE>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_GGX_SAMPLING: hipLaunchKernelGGL(k_path<T_GGX>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_BRDF_SAMPLING: hipLaunchKernelGGL(k_path<T_BRDF>, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_LIGHT_SOURCE_SAMPLING: hipLaunchKernelGGL(k_light_source, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_NEE: hipLaunchKernelGGL(k_nee, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_BRUTE_FORCE: hipLaunchKernelGGL(k_path<T_BRUTE>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_UNIFORM_SAMPLING: hipLaunchKernelGGL(k_path<T_UNIFORM>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_COSINE_WEIGHTED_SAMPLING: hipLaunchKernelGGL(k_path<T_COSINE>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_GGX_SAMPLING: hipLaunchKernelGGL(k_path<T_GGX>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_BRDF_SAMPLING: hipLaunchKernelGGL(k_path<T_BRDF>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_LIGHT_SOURCE_SAMPLING: hipLaunchKernelGGL(k_light_source, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_NEE: hipLaunchKernelGGL(k_nee, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
         case FYPRT_RESTIR_DI: case FYPRT_RESTIR_GI: {
             const uint32_t p1b = (c->rowBegin > c->halo) ? c->rowBegin - c->halo : 0u;
             const uint32_t p1e = (c->rowEnd + c->halo < c->H) ? c->rowEnd + c->halo : c->H;
             const dim3 g1 = gridFor(p1b, p1e);
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // Part 1 traces coherent primary rays only
-            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
-            else hipLaunchKernelGGL(k_gi_part1, g1, block, 0, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
+            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
+            else hipLaunchKernelGGL(k_gi_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             // The reference's spatial-neighbour coordinate is computed in unsigned arithmetic (R.cu:1916-1917): an offset
             // above the first row wraps and clamps to the LAST row.  A band that owns rows < radius therefore also needs
             // Part 1 of row H-1 (one extra row of recompute) to stay bit-identical to a single-GPU frame.
             if (c->halo > 0 && c->rowBegin < c->halo && p1e < c->H) {
                 const dim3 g2 = gridFor(c->H - 1u, c->H);
-                if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
-                else hipLaunchKernelGGL(k_gi_part1, g2, block, 0, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
+                if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g2, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
+                else hipLaunchKernelGGL(k_gi_part1, g2, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
             }
             if (tech == FYPRT_RESTIR_DI) c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
@@ -397,12 +410,20 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 }
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                 if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;
-                const int perCU = c->tuning[2] > 0 ? c->tuning[2] : 5;
-                hipLaunchKernelGGL(k_di_part2_trace, dim3((uint32_t)(c->numCUs * perCU)), block, 0, c->stream, c->dsc, fr, q);
+                int perCU = c->tuning[2];
+                if (perCU <= 0) {          // as many workgroups as registers + LDS let a CU hold (asked from the runtime once per stack size)
+                    if (c->traceOccLds != ldsBytes) {
+                        int n = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_di_part2_trace, kBlock, ldsBytes) != hipSuccess || n <= 0) n = 4;
+                        c->traceOcc = n; c->traceOccLds = ldsBytes;
+                    }
+                    perCU = c->traceOcc;
+                }
+                hipLaunchKernelGGL(k_di_part2_trace, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, c->dsc, fr, q);
                 launches = 3;
             }
-            else if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
-            else hipLaunchKernelGGL(k_gi_part2, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st);
+            else if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
+            else hipLaunchKernelGGL(k_gi_part2, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
             if (tech == FYPRT_RESTIR_DI) c->dprevFlip = !c->dprevFlip; else c->normalFlip = !c->normalFlip;
             break;
         }
@@ -542,6 +563,12 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
     if (blas_first) std::memcpy(blas_first, l.first.data(), l.first.size() * 4);
     if (blas_count) std::memcpy(blas_count, l.count.data(), l.count.size() * 4);
     if (blas_root) std::memcpy(blas_root, l.root.data(), l.root.size() * 4);
+    return FYPRT_OK;
+}
+
+int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
+    if (!c || !value || key < 0 || key >= 9) return FYPRT_EINVAL;
+    *value = (key == 8) ? effective_stack_budget(c) : c->tuning[key];
     return FYPRT_OK;
 }
 

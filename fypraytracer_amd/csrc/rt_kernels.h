@@ -63,7 +63,7 @@ RT_DEV f3 sample_dir(f3 n, f3 V, const Mat& m, f3 albedo, float ggxRoughness, ui
 
 template <int TECH>
 __global__ __launch_bounds__(kBlock) void k_path(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -188,7 +188,7 @@ RT_DEV float direct_emitter_pmf(const DevScene& sc, f3 spPos, uint32_t emitterTr
 
 // ============================================================ LIGHT_SOURCE_SAMPLING (Renderer.cu:1287-1408)
 __global__ __launch_bounds__(kBlock) void k_light_source(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_light_source(DevScene sc, DevCamera 
 
 // ============================================================ NEE (Renderer.cu:1411-1626)
 __global__ __launch_bounds__(kBlock) void k_nee(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -361,7 +361,7 @@ RT_DEV uint32_t neighbor_index(const DevCamera& cam, uint32_t W, uint32_t x, uin
 // Part 1 rows: [p1Begin, p1End) (band + halo); finished pixels (sky / emitter) go through the
 // epilogue only inside the band proper so halo rows never touch accumulation.
 __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, p1Begin, p1End, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
 }
 
 __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -492,7 +492,7 @@ RT_DEV void gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {     
 RT_DEV f3 lo3(const GISample& s) { return mk3(s.Lo[0], s.Lo[1], s.Lo[2]); }
 
 __global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, p1Begin, p1End, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam,
 }
 
 __global__ __launch_bounds__(kBlock) void k_gi_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    __shared__ int32_t s_stack[kLdsStack * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;

@@ -157,15 +157,15 @@ __global__ __launch_bounds__(kBlock) void k_di_sort_scatter(ShadowQueue q) {
 
 // per-lane in-flight ray of the persistent trace kernel
 struct LaneRay {
-    f3 o, d; RayPk pk; float tL, cut; uint32_t lightTri, pixel; f3 Lvis, Lsky;
-    int32_t cur; int top; int32_t hitTri; bool closestMode; uint32_t nBox, nTri;
+    f3 o, d; RayPk pk; float tL, cut; uint32_t lightTri, task;      // task: queue slot; pixel index and the two candidate radiances
+    int32_t cur; int top; int32_t hitTri; bool closestMode; uint32_t nBox, nTri;   // are re-read from it at the epilogue (saves 9 VGPRs)
 };
 
 RT_DEV void lane_push(int32_t* lds, int& top, int32_t v) { lds[top * kBlock] = v; ++top; }
 RT_DEV int32_t lane_pop(int32_t* lds, int& top) { --top; return lds[top * kBlock]; }
 
 __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame fr, ShadowQueue q) {
-    __shared__ int32_t s_stack[kStackDepth * kBlock];
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     int32_t* lds = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = q.counters[0];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     LaneRay r; r.cur = kExit; r.top = 0;
     bool active = false;                                           // lane owns a ray that is still being traced
     bool pending = false;                                          // lane's ray is finished, its pixel epilogue not yet run
-    f3 pendingRadiance = splat3(0.0f);
+    uint32_t outcome = 0;                                          // of the finished ray: 0 occluded, 1 light visible, 2 nothing hit (sky)
     bool more = true;                                              // wave-uniform: tasks may remain (in the queue or in this wave's chunk)
     uint32_t chunkNext = 0, chunkEnd = 0;                          // wave-uniform: this wave's claimed range of the queue
     while (true) {
@@ -182,7 +182,13 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
         if ((more && (uint32_t)__popcll(idle) >= q.refillLanes) || __ballot(active) == 0ull) {
             // finished lanes run the fused epilogue together (accumulate, tonemap, pack) — batched here so that it
             // executes once per >= kRefillLanes rays instead of once per finished ray
-            if (pending) { epilogue(fr, r.pixel, rgb1(pendingRadiance)); pending = false; }
+            if (pending) {
+                const float4* t = q.tasks + (size_t)r.task * 4;
+                const uint32_t pixel = (uint32_t)__float_as_int(t[0].w);
+                f3 radiance = splat3(0.0f);
+                if (outcome != 0u) { const float4 L = t[outcome == 1u ? 2 : 3]; radiance = mk3(L.x, L.y, L.z); }
+                epilogue(fr, pixel, rgb1(radiance)); pending = false;
+            }
         }
         if (more && (uint32_t)__popcll(idle) >= q.refillLanes) {
             if (chunkNext >= chunkEnd) {
@@ -197,11 +203,11 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             chunkNext += (want < avail) ? want : avail;
             more = chunkNext < chunkEnd || chunkEnd < total;
             if (!active && slot < chunkEnd) {
-                const float4* t = q.tasks + (size_t)(q.sortMode ? q.sorted[slot] : slot) * 4;
-                const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-                r.o = mk3(t0.x, t0.y, t0.z); r.pixel = (uint32_t)__float_as_int(t0.w);
+                r.task = q.sortMode ? q.sorted[slot] : slot;
+                const float4* t = q.tasks + (size_t)r.task * 4;
+                const float4 t0 = t[0], t1 = t[1];
+                r.o = mk3(t0.x, t0.y, t0.z);
                 r.d = mk3(t1.x, t1.y, t1.z); r.lightTri = (uint32_t)__float_as_int(t1.w);
-                r.Lvis = mk3(t2.x, t2.y, t2.z); r.Lsky = mk3(t3.x, t3.y, t3.z);
                 r.pk = make_raypk(r.o, safe_inv(r.d.x), safe_inv(r.d.y), safe_inv(r.d.z));
                 // light triangle first (same Möller–Trumbore as trace_shadow)
                 float tL = -1.0f;
@@ -267,9 +273,9 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             }
             // finished lanes: select the pixel's radiance, park it until the next batched epilogue
             if (active && r.cur == kExit) {
-                pendingRadiance = splat3(0.0f);
-                if (r.hitTri == (int32_t)r.lightTri) pendingRadiance = r.Lvis;          // R.cu:2016-2027
-                else if (r.closestMode && r.hitTri < 0) pendingRadiance = r.Lsky;       // R.cu:2028-2031
+                outcome = 0u;
+                if (r.hitTri == (int32_t)r.lightTri) outcome = 1u;                      // R.cu:2016-2027: Lvis
+                else if (r.closestMode && r.hitTri < 0) outcome = 2u;                   // R.cu:2028-2031: Lsky
                 pending = true;
                 if (counting) {
                     // same totals as trace_shadow: the fallback counts its light test, then a full closest-hit ray

@@ -236,7 +236,7 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
 /* Performance knobs that never change results (A/B experiments; defaults are the measured best).
  * key 0: tile order — 0 linear, 1 one contiguous eighth of the tiles per XCD, 2 every 8th tile row per XCD.
  * key 1: ReSTIR DI Part 2 — 0 one thread per pixel, 1 setup kernel + shadow-task queue + persistent trace waves.
- * key 2: persistent workgroups per CU for the trace kernel (default 5 = LDS-resident maximum).
+ * key 2: persistent workgroups per CU for the trace kernel (default 0 = as many as LDS and registers allow, at most 5).
  * key 3: 1 = counting-sort the shadow tasks by light bin before tracing (slotted tasks + histogram matrix + column scan +
  *        scatter, no global atomics).  Default 0: measured +0.04 ms for the sort and no faster trace — shadow-ray cost is
  *        dominated by the geometry around the ray ORIGIN, which the unsorted tile order already keeps coherent.
@@ -245,10 +245,14 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
  *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).
  * key 7: the same for every other kernel (default 0: measured neutral or slightly negative there).
- * key 8: pending-entry budget of the traversal stack rule (default and maximum 31, clamped from below to the tree's level
- *        count): siblings are pushed one by one while pending + 2 + levels(node) <= budget, else as one resume entry.
- *        Unlike keys 0-7 a lower value changes the visiting order (exact-t ties may resolve differently); for tests. */
+ * key 8: pending-entry budget of the traversal stack rule (default 0 = tree levels + 8, at least 19; at most 31; always
+ *        clamped from below to the tree's level count): siblings are pushed one by one while
+ *        pending + 2 + levels(node) <= budget, else as one resume entry; the LDS stack holds budget + 1 entries per thread.
+ *        Unlike keys 0-7 the value can change the visiting order (exact-t ties may resolve differently). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
+/* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
+ * traversal must use too). */
+int fyprt_get_tuning(fyprt_context* ctx, int key, int* value);
 
 /* Library / build identification ("fyprt <version> gfx950 ..."). */
 const char* fyprt_version(void);

@@ -140,7 +140,7 @@ def test_bit_exact_with_resume_entries(gpu, oracle_built, tech):
     ctx.resize(W, H)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
-    ctx.set_tuning(8, 0)                                   # clamped from below to the level count
+    ctx.set_tuning(8, 1)                                   # clamped from below to the level count
     bvh = ctx.export_bvh()
     orc = Oracle(sc, W, H)
     orc.set_camera(cam)
