@@ -60,7 +60,7 @@ struct fyprt_context {
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[9] = {2, 1, 0, 0, 128, 24, 32, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[9] = {2, 1, 0, 0, 128, 24, 24, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 

@@ -18,3 +18,11 @@ print("no temporal    ", run(use_temporal_reuse=0,use_spatial_reuse=1,light_cand
 print("1 candidate    ", run(use_temporal_reuse=0,use_spatial_reuse=1,light_candidate_count=1))
 print("no spatial     ", run(use_temporal_reuse=1,use_spatial_reuse=0,light_candidate_count=4))
 print("16 candidates  ", run(use_temporal_reuse=1,use_spatial_reuse=1,light_candidate_count=16))
+def run_primary():
+    st=capi.Settings(technique=0, sky_color=(0,0,0), light_bounces=0)
+    ctx.reset_frame_index(); ks=[]
+    for f in range(14):
+        st.rand_seed=f+1; s=ctx.render(st)
+        if f>=4: ks.append(s.kernel_ms)
+    return round(float(np.median(ks)),4)
+print("primary ray only (brute force, 0 bounces)", run_primary())
