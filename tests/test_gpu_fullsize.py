@@ -1,0 +1,115 @@
+"""BASELINE.json's full sizes (1M-triangle hall, 1920x1080; 3840x2160 for GI), where the CPU oracle would take minutes per
+frame: size-independent properties instead of a per-pixel comparison —
+  * determinism: two independent contexts produce bit-identical frames (checksum of per-row checksums);
+  * a frame split into 8 row bands (the multi-GPU decomposition, fyprt_set_rows + halo) stitches to the single-context frame
+    bit for bit on frame 1 (ReSTIR) / every frame (pure per-pixel techniques);
+  * ray accounting: one primary ray per pixel, per-launch counters add up, a second instrumented frame counts the same;
+  * a bounded sample of the full-size frame (64 rows) against the oracle running the same traversal, bit-exact.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from common import bits_equal, settings_for
+from fypraytracer_amd import capi, multigpu, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hall():
+    return scenes.hall_scene()
+
+
+def _checksum(img, acc):
+    rows = [zlib.crc32(acc[y].tobytes(), zlib.crc32(img[y].tobytes())) for y in range(img.shape[0])]
+    return zlib.crc32(np.asarray(rows, dtype=np.uint32).tobytes())
+
+
+def _frames(sc, cam, W, H, tech, frames, rows=None, halo=0):
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    if rows:
+        ctx.set_rows(rows[0], rows[1], halo)
+    ctx.upload_scene(sc)
+    ctx.set_camera(cam)
+    st = settings_for(tech)
+    for f in range(frames):
+        st.rand_seed = f + 1
+        ctx.render(st)
+    img, acc = ctx.readback()
+    ctx.close()
+    return img, acc
+
+
+def test_restir_di_1080p_is_deterministic_and_bands_stitch(hall):
+    W, H = 1920, 1080
+    cam = scenes.hall_camera(W, H)
+    a = _frames(hall, cam, W, H, capi.RESTIR_DI, 3)
+    b = _frames(hall, cam, W, H, capi.RESTIR_DI, 3)
+    assert _checksum(*a) == _checksum(*b)
+    assert np.isfinite(a[1]).all() and (a[0] >> 24 == 0xFF).all()
+    # 8-way row split, frame 1: every band bit-identical to the same rows of the single-context frame
+    full_img, full_acc = _frames(hall, cam, W, H, capi.RESTIR_DI, 1)
+    st = settings_for(capi.RESTIR_DI)
+    halo = multigpu.halo_rows(st, capi.RESTIR_DI, 8)
+    for rank in (0, 3, 7):                                  # first, interior and last band (top wrap, two halos, bottom clamp)
+        y0, y1 = multigpu.band_rows(H, 8, rank)
+        img, acc = _frames(hall, cam, W, H, capi.RESTIR_DI, 1, rows=(y0, y1), halo=halo)
+        assert np.array_equal(img[y0:y1], full_img[y0:y1]) and bits_equal(acc[y0:y1], full_acc[y0:y1]).all(), rank
+
+
+def test_restir_di_1080p_ray_accounting(hall):
+    W, H = 1920, 1080
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.upload_scene(hall)
+    ctx.set_camera(scenes.hall_camera(W, H))
+    ctx.set_ray_counting(True)
+    st = settings_for(capi.RESTIR_DI)
+    seen = []
+    for f in range(2):
+        st.rand_seed = 1                                     # same seed, frame index differs -> different random numbers, same geometry
+        s = ctx.render(st)
+        assert sum(s.part_rays) == s.rays and sum(s.part_box_tests) == s.box_tests and sum(s.part_tri_tests) == s.tri_tests
+        assert s.part_rays[0] == W * H                       # one primary ray per pixel in Part 1
+        assert s.part_rays[1] == 0 and 0 < s.part_rays[2] <= W * H   # setup traces nothing, at most one shadow ray per pixel
+        assert s.hits <= s.rays and s.box_tests > s.rays
+        seen.append((s.part_rays[0], s.part_box_tests[0], s.part_tri_tests[0]))
+    assert seen[0] == seen[1]                                # primary rays do not depend on the frame index
+    ctx.close()
+
+
+def test_restir_gi_4k_is_deterministic(hall):
+    W, H = 3840, 2160
+    cam = scenes.hall_camera(W, H)
+    a = _frames(hall, cam, W, H, capi.RESTIR_GI, 2)
+    b = _frames(hall, cam, W, H, capi.RESTIR_GI, 2)
+    assert _checksum(*a) == _checksum(*b)
+    assert (a[0] >> 24 == 0xFF).all()
+
+
+def test_band_of_the_full_size_frame_against_the_oracle(hall, oracle_built):
+    """64 rows of the 1080p ReSTIR DI frame (band + 30-row halo, as rank 3 of 8 would render them) against the oracle's
+    restatement of the same traversal over the exported 1M-triangle tree: bit-exact."""
+    from oraclelib import Oracle
+    W, H = 1920, 1080
+    y0, y1, halo = 500, 564, 30
+    cam = scenes.hall_camera(W, H)
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.set_rows(y0, y1, halo)
+    ctx.upload_scene(hall)
+    ctx.set_camera(cam)
+    orc = Oracle(hall, W, H)
+    orc.set_camera(cam)
+    orc.use_product_bvh(ctx.export_bvh())
+    st = settings_for(capi.RESTIR_DI)
+    st.rand_seed = 1
+    ctx.render(st)
+    orc.render(st, rows=(y0, y1), halo=halo)
+    img, acc = ctx.readback()
+    assert bits_equal(acc[y0:y1], orc.accum()[y0:y1]).all() and np.array_equal(img[y0:y1], orc.image()[y0:y1])
+    assert orc.product_max_stack() <= 31
+    ctx.close()
