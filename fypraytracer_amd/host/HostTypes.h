@@ -2,6 +2,7 @@
 // Texture.cuh, Scene.h, Camera.h) — just enough of the scene API to drive the facade headlessly.
 // Byte layouts equal the reference's (Vertex 32, Triangle 52, Material 44).
 #pragma once
+#include "TextureIO.h"
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -19,13 +20,23 @@ struct Material {
     bool isUseAlbedoMap = false; vec3 albedo{1.0f, 0.0f, 1.0f}; uint32_t albedoMapIndex = 0xFFFFFFFFu;
     float roughness = 1.0f, metallic = 0.0f; vec3 emissionColor; float emissionPower = 0.0f;
 };
-struct Texture { uint32_t* pixels = nullptr; uint32_t width = 0, height = 0; };
+struct Texture { uint32_t* pixels = nullptr; uint32_t width = 0, height = 0; std::string fileName; };
 struct Mesh { uint32_t vertexStart = 0, vertexCount = 0, indexStart = 0, indexCount = 0; int materialIndex = 0; };
 static_assert(sizeof(Vertex) == 32 && sizeof(Triangle) == 52 && sizeof(Material) == 44, "reference layouts");
 
 struct Scene {
     std::vector<Vertex> worldVertices; std::vector<Triangle> triangles; std::vector<uint32_t> emissiveTriangles;
     std::vector<Mesh> meshes; std::vector<Material> materials; std::vector<Texture> textures;
+    std::vector<TextureImage> textureStorage;   // owns the pixels of textures loaded through LoadTexture
+    // Scene::LoadTexture / Texture::Texture(path) (Scene.cpp:225-260, Texture.cu:8-40): PNG -> ABGR words; returns the texture index or -1
+    int LoadTexture(const std::string& path) {
+        TextureImage img;
+        if (!LoadTexturePNG(path, img)) return -1;
+        textureStorage.push_back(std::move(img));
+        textures.clear();                       // storage may have moved: rebuild the views
+        for (TextureImage& t : textureStorage) { Texture v; v.pixels = t.pixels.data(); v.width = t.width; v.height = t.height; v.fileName = t.fileName; textures.push_back(v); }
+        return (int)textures.size() - 1;
+    }
     // Scene::AddNewMeshToScene (Scene.cpp:9-92) for already-world-space geometry (identity transform)
     Mesh* AddNewMeshToScene(const std::vector<Vertex>& meshVertices, const std::vector<uint32_t>& indices, int materialIndex) {
         Mesh mesh; mesh.vertexStart = (uint32_t)worldVertices.size(); mesh.vertexCount = (uint32_t)meshVertices.size();

@@ -324,13 +324,17 @@ def _stripe_texture(n=256):
     return ((255 << 24) | (b.astype(np.uint32) << 16) | (g.astype(np.uint32) << 8) | r.astype(np.uint32)).astype(np.uint32)
 
 
-def banana_scene(obj_path=None):
+def banana_scene(obj_path=None, png_path=None):
     """BASELINE config 2: one ~3.2k-triangle mesh as a single BLAS, textured diffuse material, transform of
     WalnutApp.cpp:135-137 (pos (0,-3,0), rot (90,0,0)), a floor quad and one emissive quad above.
-    `obj_path` loads the reference's own banana.obj when available (never on the GPU box); otherwise the
-    procedural stand-in with the same triangle count is used."""
+    `obj_path` / `png_path` load the reference's own banana.obj / bananaDiffuse.png when available (never on the GPU
+    box); otherwise the procedural stand-in with the same triangle count and a procedural texture are used."""
     sc = Scene()
-    sc.textures = [_stripe_texture()]
+    if png_path is not None:
+        from . import texture
+        sc.textures = [texture.load_png(png_path)]                     # Texture::Texture (Texture.cu:8-40)
+    else:
+        sc.textures = [_stripe_texture()]
     sc.materials = [
         Material(albedo=(0.9, 0.8, 0.2), roughness=1.0, metallic=0.0, is_use_albedo_map=True, albedo_map_index=0),   # matBanana, WalnutApp.cpp:76-80
         Material(albedo=(1, 1, 1), roughness=1.0, metallic=0.0),
