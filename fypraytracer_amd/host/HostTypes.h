@@ -21,10 +21,71 @@ struct Material {
     float roughness = 1.0f, metallic = 0.0f; vec3 emissionColor; float emissionPower = 0.0f;
 };
 struct Texture { uint32_t* pixels = nullptr; uint32_t width = 0, height = 0; std::string fileName; };
-struct Mesh { uint32_t vertexStart = 0, vertexCount = 0, indexStart = 0, indexCount = 0; int materialIndex = 0; };
+struct Mesh {                                   // Mesh.h: ranges into the scene arrays + the transform the UI edits
+    uint32_t vertexStart = 0, vertexCount = 0, indexStart = 0, indexCount = 0; int materialIndex = 0;
+    vec3 position{0, 0, 0}, rotation{0, 0, 0}, scale{1, 1, 1}; mat4 worldTransformMatrix;
+    // Mesh::UpdateWorldTransform: T * yawPitchRoll(radians(rot.y), radians(rot.x), radians(rot.z)) * S (glm::yawPitchRoll,
+    // angles and trigonometry in double, entries rounded to float; products in float, column by column)
+    static void UpdateWorldTransform(Mesh& m) {
+        const double d2r = 3.14159265358979323846 / 180.0;
+        const double yaw = m.rotation.y * d2r, pitch = m.rotation.x * d2r, roll = m.rotation.z * d2r;
+        const double ch = std::cos(yaw), sh = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch), cb = std::cos(roll), sb = std::sin(roll);
+        mat4 R;
+        R.m[0] = (float)(ch * cb + sh * sp * sb); R.m[1] = (float)(sb * cp); R.m[2] = (float)(-sh * cb + ch * sp * sb);
+        R.m[4] = (float)(-ch * sb + sh * sp * cb); R.m[5] = (float)(cb * cp); R.m[6] = (float)(sb * sh + ch * sp * cb);
+        R.m[8] = (float)(sh * cp); R.m[9] = (float)(-sp); R.m[10] = (float)(ch * cp);
+        mat4 T; T.m[12] = m.position.x; T.m[13] = m.position.y; T.m[14] = m.position.z;
+        mat4 S; S.m[0] = m.scale.x; S.m[5] = m.scale.y; S.m[10] = m.scale.z;
+        m.worldTransformMatrix = Mul(Mul(T, R), S);
+    }
+    static mat4 Mul(const mat4& a, const mat4& b) {          // (a*b)[col] = sum_k a[k] * b[col][k], accumulated in k order
+        mat4 o;
+        for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc = acc + a.m[k * 4 + r] * b.m[j * 4 + k];
+            o.m[j * 4 + r] = acc;
+        }
+        return o;
+    }
+    // the vertex loop of Scene::AddNewMeshToScene / SceneManager (Scene.cpp:42-51, SceneManager.cpp:30-41):
+    // position = (M * (p, 1)).xyz / w, normal = normalize((M * (n, 0)).xyz) — the model matrix, not its inverse transpose
+    Vertex ToWorld(const Vertex& v) const {
+        const float* M = worldTransformMatrix.m; Vertex o = v;
+        const float px = (M[0] * v.position.x + M[4] * v.position.y) + (M[8] * v.position.z + M[12]);
+        const float py = (M[1] * v.position.x + M[5] * v.position.y) + (M[9] * v.position.z + M[13]);
+        const float pz = (M[2] * v.position.x + M[6] * v.position.y) + (M[10] * v.position.z + M[14]);
+        const float pw = (M[3] * v.position.x + M[7] * v.position.y) + (M[11] * v.position.z + M[15]);
+        o.position = vec3{px / pw, py / pw, pz / pw};
+        const float nx = (M[0] * v.normal.x + M[4] * v.normal.y) + (M[8] * v.normal.z);
+        const float ny = (M[1] * v.normal.x + M[5] * v.normal.y) + (M[9] * v.normal.z);
+        const float nz = (M[2] * v.normal.x + M[6] * v.normal.y) + (M[10] * v.normal.z);
+        const float inv = 1.0f / std::sqrt((nx * nx + ny * ny) + nz * nz);
+        o.normal = vec3{nx * inv, ny * inv, nz * inv};
+        return o;
+    }
+};
 static_assert(sizeof(Vertex) == 32 && sizeof(Triangle) == 52 && sizeof(Material) == 44, "reference layouts");
 
+struct Scene;
+// SceneManager (Classes/Managers/SceneManager.{h,cpp}): the UI queues mesh / material edits (WalnutApp.cpp:662, :715) and
+// PerformAllSceneUpdates applies them before the next frame and raises the renderer's scene-dirty flag (:776).  Both queues
+// start with 20 default entries as the reference's do (SceneManager.h:25-26), so the first call always raises the flag; the
+// emissive-triangle list is not refreshed here (the reference builds it only at load).  Acceleration structures are this
+// build's own and are rebuilt by the library when the flag makes the facade upload the scene again.
+struct SceneManager {
+    struct MeshUpdateParam {
+        MeshUpdateParam(bool t, bool m, uint32_t i) : meshTransformToBeUpdated(t), meshMatToBeUpdated(m), meshIndex(i) {}
+        MeshUpdateParam() = default;
+        bool meshTransformToBeUpdated = false, meshMatToBeUpdated = false; uint32_t meshIndex = 0xFFFFFFFFu;
+    };
+    std::vector<MeshUpdateParam> meshesToUpdate{20};
+    std::vector<uint32_t> materialsToUpdate = std::vector<uint32_t>(20);
+    template <class RendererT> void PerformAllSceneUpdates(Scene& scene, RendererT& renderer);
+};
+
 struct Scene {
+    std::vector<Vertex> vertices;                  // object space (Scene::vertices)
+    SceneManager sceneManager;
     std::vector<Vertex> worldVertices; std::vector<Triangle> triangles; std::vector<uint32_t> emissiveTriangles;
     std::vector<Mesh> meshes; std::vector<Material> materials; std::vector<Texture> textures;
     std::vector<TextureImage> textureStorage;   // owns the pixels of textures loaded through LoadTexture
@@ -37,11 +98,17 @@ struct Scene {
         for (TextureImage& t : textureStorage) { Texture v; v.pixels = t.pixels.data(); v.width = t.width; v.height = t.height; v.fileName = t.fileName; textures.push_back(v); }
         return (int)textures.size() - 1;
     }
-    // Scene::AddNewMeshToScene (Scene.cpp:9-92) for already-world-space geometry (identity transform)
+    // Scene::AddNewMeshToScene (Scene.cpp:9-92): object-space vertices + transform -> world vertices, triangles, mesh record
     Mesh* AddNewMeshToScene(const std::vector<Vertex>& meshVertices, const std::vector<uint32_t>& indices, int materialIndex) {
+        return AddNewMeshToScene(meshVertices, indices, vec3{0, 0, 0}, vec3{0, 0, 0}, vec3{1, 1, 1}, materialIndex);
+    }
+    Mesh* AddNewMeshToScene(const std::vector<Vertex>& meshVertices, const std::vector<uint32_t>& indices, const vec3& pos, const vec3& rotation,
+                            const vec3& scale, int materialIndex) {
         Mesh mesh; mesh.vertexStart = (uint32_t)worldVertices.size(); mesh.vertexCount = (uint32_t)meshVertices.size();
         mesh.indexStart = (uint32_t)triangles.size() * 3u; mesh.indexCount = (uint32_t)indices.size(); mesh.materialIndex = materialIndex;
-        worldVertices.insert(worldVertices.end(), meshVertices.begin(), meshVertices.end());
+        mesh.position = pos; mesh.rotation = rotation; mesh.scale = scale; Mesh::UpdateWorldTransform(mesh);
+        vertices.insert(vertices.end(), meshVertices.begin(), meshVertices.end());
+        for (const Vertex& v : meshVertices) worldVertices.push_back(mesh.ToWorld(v));
         for (size_t i = 0; i + 2 < indices.size(); i += 3) {
             Triangle t; t.v0 = mesh.vertexStart + indices[i]; t.v1 = mesh.vertexStart + indices[i + 1]; t.v2 = mesh.vertexStart + indices[i + 2];
             t.materialIndex = materialIndex; triangles.push_back(t);
@@ -57,6 +124,27 @@ struct Scene {
         }
     }
 };
+
+template <class RendererT> void SceneManager::PerformAllSceneUpdates(Scene& scene, RendererT& renderer) {   // SceneManager.cpp:6-130
+    if (!materialsToUpdate.empty()) renderer.SetSceneToBeUpdatedFlag(true);
+    for (const MeshUpdateParam& u : meshesToUpdate) {
+        if (!(u.meshTransformToBeUpdated || u.meshMatToBeUpdated)) continue;
+        Mesh& mesh = scene.meshes[u.meshIndex];
+        if (u.meshTransformToBeUpdated) {
+            Mesh::UpdateWorldTransform(mesh);
+            for (uint32_t i = 0; i < mesh.vertexCount; ++i) {
+                const Vertex w = mesh.ToWorld(scene.vertices[mesh.vertexStart + i]);
+                scene.worldVertices[mesh.vertexStart + i].position = w.position; scene.worldVertices[mesh.vertexStart + i].normal = w.normal;
+            }
+            renderer.SetSceneToBeUpdatedFlag(true);
+        }
+        if (u.meshMatToBeUpdated) {
+            for (uint32_t t = mesh.indexStart / 3; t < mesh.indexStart / 3 + mesh.indexCount / 3; ++t) scene.triangles[t].materialIndex = mesh.materialIndex;
+            renderer.SetSceneToBeUpdatedFlag(true);
+        }
+    }
+    meshesToUpdate.clear(); materialsToUpdate.clear();
+}
 
 // Camera.h:9-83 with the matrices filled by perspectiveFov / lookAt (glm RH, [-1,1] depth) and a general 4x4 inverse.
 class Camera {

@@ -173,6 +173,21 @@ class Scene:
     triangles: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=TRIANGLE_DTYPE))
     meshes: list = field(default_factory=list)            # (firstTriangle, triangleCount, materialIndex)
     emissive_triangles: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.uint32))
+    vertices: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=VERTEX_DTYPE))   # Scene::vertices: object space
+    mesh_transforms: list = field(default_factory=list)   # per mesh: dict(pos, rotation, scale, vertex_start, vertex_count) (Mesh.h transform members)
+    scene_manager: "SceneManager" = None                  # Scene::sceneManager (Scene.h), created on first use
+
+    @staticmethod
+    def _to_world(positions, normals, pos, rotation, scale_):
+        """Mesh::UpdateWorldTransform + the vertex loop of Scene::AddNewMeshToScene / SceneManager (Scene.cpp:42-51,
+        SceneManager.cpp:30-41): transform = T * yawPitchRoll(ry, rx, rz) * S, position / w, normal with w = 0, normalised."""
+        m = _matmul(_matmul(translate(pos), yaw_pitch_roll(math.radians(rotation[1]), math.radians(rotation[0]), math.radians(rotation[2]))), scale(scale_))
+        p4 = (m[0][None, :] * positions[:, 0:1] + m[1][None, :] * positions[:, 1:2]) + (m[2][None, :] * positions[:, 2:3] + m[3][None, :])
+        wp = (p4[:, :3] / p4[:, 3:4]).astype(F)
+        n4 = (m[0][None, :] * normals[:, 0:1] + m[1][None, :] * normals[:, 1:2]) + (m[2][None, :] * normals[:, 2:3])
+        nl = np.sqrt((n4[:, 0] * n4[:, 0] + n4[:, 1] * n4[:, 1]) + n4[:, 2] * n4[:, 2])
+        wn = (n4[:, :3] * (F(1) / nl)[:, None]).astype(F)
+        return wp, wn
 
     def add_new_mesh_to_scene(self, positions, normals, uvs, indices, pos=(0, 0, 0), rotation=(0, 0, 0),
                               scale_=(1, 1, 1), material_index=0):
@@ -182,12 +197,7 @@ class Scene:
         normals = np.asarray(normals, dtype=F).reshape(-1, 3)
         uvs = np.asarray(uvs, dtype=F).reshape(-1, 2)
         indices = np.asarray(indices, dtype=np.uint32).reshape(-1, 3)
-        m = _matmul(_matmul(translate(pos), yaw_pitch_roll(math.radians(rotation[1]), math.radians(rotation[0]), math.radians(rotation[2]))), scale(scale_))
-        p4 = (m[0][None, :] * positions[:, 0:1] + m[1][None, :] * positions[:, 1:2]) + (m[2][None, :] * positions[:, 2:3] + m[3][None, :])
-        wp = (p4[:, :3] / p4[:, 3:4]).astype(F)
-        n4 = (m[0][None, :] * normals[:, 0:1] + m[1][None, :] * normals[:, 1:2]) + (m[2][None, :] * normals[:, 2:3])
-        nl = np.sqrt((n4[:, 0] * n4[:, 0] + n4[:, 1] * n4[:, 1]) + n4[:, 2] * n4[:, 2])
-        wn = (n4[:, :3] * (F(1) / nl)[:, None]).astype(F)
+        wp, wn = self._to_world(positions, normals, pos, rotation, scale_)
         v = np.zeros(len(positions), dtype=VERTEX_DTYPE)
         v["position"], v["normal"], v["uv"] = wp, wn, uvs
         vstart = len(self.world_vertices)
@@ -195,10 +205,19 @@ class Scene:
         t["v0"], t["v1"], t["v2"] = (indices[:, 0] + vstart, indices[:, 1] + vstart, indices[:, 2] + vstart)
         t["materialIndex"] = material_index
         first = len(self.triangles)
+        lv = np.zeros(len(positions), dtype=VERTEX_DTYPE)
+        lv["position"], lv["normal"], lv["uv"] = positions, normals, uvs
+        self.vertices = np.concatenate([self.vertices, lv])
         self.world_vertices = np.concatenate([self.world_vertices, v])
         self.triangles = np.concatenate([self.triangles, t])
         self.meshes.append((first, len(indices), material_index))
+        self.mesh_transforms.append({"pos": tuple(pos), "rotation": tuple(rotation), "scale": tuple(scale_), "vertex_start": vstart, "vertex_count": len(positions)})
         return len(self.meshes) - 1
+
+    def manager(self):
+        if self.scene_manager is None:
+            self.scene_manager = SceneManager()
+        return self.scene_manager
 
     def init_scene_emissive_triangles(self):  # Scene.cpp:209-221
         em = np.array([float(np.dot(m.get_emission(), m.get_emission())) > 0.0 for m in self.materials])
@@ -217,3 +236,65 @@ class Scene:
         for i, (f, c, mi) in enumerate(self.meshes):
             a[i] = (f, c, mi)
         return a
+
+
+class SceneManager:
+    """SceneManager (Classes/Managers/SceneManager.{h,cpp}): the UI queues mesh / material edits, and
+    PerformAllSceneUpdates applies them before the next frame and raises the renderer's scene-dirty flag
+    (WalnutApp.cpp:662, :715, :776).  Kept as the reference does it:
+      * a moved mesh's world vertices are recomputed from the object-space copy with the mesh's new transform
+        (SceneManager.cpp:24-41; triangle boxes :46-60 are this build's builder's business);
+      * a mesh material change rewrites the material index of its triangles (:69-80);
+      * the emissive-triangle list is NOT refreshed here (the reference only builds it at load, Scene.cpp:284,
+        WalnutApp.cpp:510) — a material that starts or stops emitting changes NEE's light trees (rebuilt from the materials at
+        upload) but not ReSTIR's candidate list until init_scene_emissive_triangles() is called again;
+      * both queues start with 20 default entries (SceneManager.h:25-26: `{20}`), so the very first call always raises
+        the dirty flag even if nothing was edited.
+    `renderer` is anything with set_scene_to_be_updated_flag(bool) (the facade) or None."""
+
+    def __init__(self):
+        self.meshes_to_update = [(False, False, 0xFFFFFFFF)] * 20       # (transform changed, material changed, mesh index)
+        self.materials_to_update = [0] * 20
+
+    def perform_all_scene_updates(self, scene, renderer=None):
+        dirty = False
+        if self.materials_to_update:
+            dirty = True
+        for transform_changed, material_changed, mi in self.meshes_to_update:
+            if not (transform_changed or material_changed):
+                continue
+            first, count, material_index = scene.meshes[mi]
+            tr = scene.mesh_transforms[mi]
+            if transform_changed:
+                a, n = tr["vertex_start"], tr["vertex_count"]
+                wp, wn = Scene._to_world(scene.vertices["position"][a:a + n], scene.vertices["normal"][a:a + n], tr["pos"], tr["rotation"], tr["scale"])
+                scene.world_vertices["position"][a:a + n] = wp
+                scene.world_vertices["normal"][a:a + n] = wn
+                dirty = True
+            if material_changed:
+                scene.triangles["materialIndex"][first:first + count] = material_index
+                dirty = True
+        self.meshes_to_update = []
+        self.materials_to_update = []
+        if dirty and renderer is not None:
+            renderer.set_scene_to_be_updated_flag(True)
+        return dirty
+
+    # the two UI edits that feed the queues (WalnutApp.cpp:620-662, :690-715)
+    def set_mesh_transform(self, scene, mesh_index, pos=None, rotation=None, scale_=None):
+        tr = scene.mesh_transforms[mesh_index]
+        if pos is not None:
+            tr["pos"] = tuple(pos)
+        if rotation is not None:
+            tr["rotation"] = tuple(rotation)
+        if scale_ is not None:
+            tr["scale"] = tuple(scale_)
+        self.meshes_to_update.append((True, False, mesh_index))
+
+    def set_mesh_material(self, scene, mesh_index, material_index):
+        first, count, _ = scene.meshes[mesh_index]
+        scene.meshes[mesh_index] = (first, count, material_index)
+        self.meshes_to_update.append((False, True, mesh_index))
+
+    def material_edited(self, material_index):
+        self.materials_to_update.append(material_index)
