@@ -169,13 +169,24 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     int32_t* lds = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = q.counters[0];
+    // Work distribution: every wave owns one chunk statically (wave w: tasks [w * chunk, (w + 1) * chunk)), further chunks are
+    // stolen from a shared head that starts behind the static ones.  The chunk is q.chunk when there is plenty of work and an
+    // even share when there are fewer tasks than the grid has lanes (a narrow multi-GPU band).  Without the static part all
+    // 6144 waves of the grid hit the one head word at start-up: 70 us of serialised atomics (88 per us) before the last wave
+    // had anything to do — most of the kernel's 0.21 ms floor on small bands.
+    const uint32_t nWaves = gridDim.x * (uint32_t)(kBlock / 64), myWave = blockIdx.x * (uint32_t)(kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t share = (total + nWaves - 1u) / nWaves;
+    const uint32_t chunk = share < q.chunk ? (share < 16u ? 16u : share) : q.chunk;
+    const uint32_t dynBase = nWaves * chunk;
+    const bool hasDyn = dynBase < total;                           // otherwise the static chunks cover the whole queue: no atomics at all
     const bool counting = sc.rayCounter != nullptr;
     LaneRay r; r.cur = kExit; r.top = 0;
     bool active = false;                                           // lane owns a ray that is still being traced
     bool pending = false;                                          // lane's ray is finished, its pixel epilogue not yet run
     uint32_t outcome = 0;                                          // of the finished ray: 0 occluded, 1 light visible, 2 nothing hit (sky)
-    bool more = true;                                              // wave-uniform: tasks may remain (in the queue or in this wave's chunk)
-    uint32_t chunkNext = 0, chunkEnd = 0;                          // wave-uniform: this wave's claimed range of the queue
+    bool more = total != 0u;                                       // wave-uniform: tasks may remain (in the queue or in this wave's chunk)
+    uint32_t chunkNext = myWave * chunk < total ? myWave * chunk : total;     // wave-uniform: this wave's claimed range of the queue
+    uint32_t chunkEnd = (myWave + 1u) * chunk < total ? (myWave + 1u) * chunk : total;
     while (true) {
         // ---------------- refill: idle lanes take the next tasks of the wave's chunk; a new chunk is stolen from the queue head when it runs dry
         const unsigned long long idle = __ballot(!active);
@@ -191,17 +202,17 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             }
         }
         if (more && (uint32_t)__popcll(idle) >= q.refillLanes) {
-            if (chunkNext >= chunkEnd) {
+            if (chunkNext >= chunkEnd && hasDyn) {
                 uint32_t base = 0;
-                if (lane == 0u) base = atomicAdd(q.counters + 1, q.chunk);
+                if (lane == 0u) base = dynBase + atomicAdd(q.counters + 1, chunk);
                 base = (uint32_t)__shfl((int)base, 0);
                 chunkNext = base < total ? base : total;
-                chunkEnd = (base + q.chunk < total) ? base + q.chunk : total;
+                chunkEnd = (base + chunk < total) ? base + chunk : total;
             }
             const uint32_t slot = chunkNext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t want = (uint32_t)__popcll(idle), avail = chunkEnd - chunkNext;
             chunkNext += (want < avail) ? want : avail;
-            more = chunkNext < chunkEnd || chunkEnd < total;
+            more = chunkNext < chunkEnd || (hasDyn && chunkEnd < total);
             if (!active && slot < chunkEnd) {
                 r.task = q.sortMode ? q.sorted[slot] : slot;
                 const float4* t = q.tasks + (size_t)r.task * 4;

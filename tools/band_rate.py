@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--all-ranks", action="store_true", help="every band of each split instead of one interior band")
     a = ap.parse_args()
     W, H = 1920, 1080
     sc, cam = scenes.hall_scene(), scenes.hall_camera(W, H)
@@ -25,8 +26,7 @@ def main():
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
     st = capi.Settings(technique=capi.RESTIR_DI, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
-    for n in a.n:
-        rank = n // 2 if n > 1 else 0                                  # an interior band (two halos)
+    for n, rank in [(n, r) for n in a.n for r in (range(n) if a.all_ranks else [n // 2 if n > 1 else 0])]:   # default: an interior band (two halos)
         y0, y1 = multigpu.band_rows(H, n, rank)
         ctx.set_rows(y0, y1, multigpu.halo_rows(st, capi.RESTIR_DI, n))
         ctx.reset_frame_index()
@@ -47,7 +47,7 @@ def main():
             ks.append(sum(ms[:nl])); parts.append(ms[:4])
         import numpy as np
         parts = np.median(np.array(parts), axis=0).round(4).tolist()
-        print(json.dumps({"n": n, "rows": [y0, y1], "wall_ms_per_frame": round(wall / a.frames * 1e3, 4), "kernel_ms_per_frame": round(sum(ks) / len(ks), 4),
+        print(json.dumps({"n": n, "rank": rank, "rows": [y0, y1], "wall_ms_per_frame": round(wall / a.frames * 1e3, 4), "kernel_ms_per_frame": round(sum(ks) / len(ks), 4),
                           "host_enqueue_ms_per_frame": round(t_enq / a.frames * 1e3, 4), "launch_ms": parts}), flush=True)
     ctx.close()
 
