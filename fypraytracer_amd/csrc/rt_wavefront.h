@@ -18,7 +18,7 @@
 namespace rt {
 
 struct ShadowQueue {
-    float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes;
+    float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes, staticChunks;
     // light-sorted mode (tuning key 3): tasks are slotted per setup workgroup, a counting sort over kSortBins light bins
     // produces `sorted` (task slots in bin order) without a single global atomic
     uint32_t sortMode, numGroups; uint32_t* counts; uint8_t* keys; uint16_t* hist; uint32_t* binOffset; uint32_t* binTotal; uint32_t* sorted;
@@ -169,15 +169,18 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     int32_t* lds = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = q.counters[0];
-    // Work distribution: every wave owns one chunk statically (wave w: tasks [w * chunk, (w + 1) * chunk)), further chunks are
-    // stolen from a shared head that starts behind the static ones.  The chunk is q.chunk when there is plenty of work and an
-    // even share when there are fewer tasks than the grid has lanes (a narrow multi-GPU band).  Without the static part all
-    // 6144 waves of the grid hit the one head word at start-up: 70 us of serialised atomics (88 per us) before the last wave
-    // had anything to do — most of the kernel's 0.21 ms floor on small bands.
+    // Work distribution: every wave owns the first `first` tasks of its own slice statically (wave w: [w * first, (w + 1) * first)),
+    // further chunks are stolen from a shared head that starts behind the static slices.  `first` is key 9 x chunk when there is
+    // plenty of work and an even share when the queue is shorter than that (a narrow multi-GPU band): then no atomic is
+    // issued at all.  Without the static part all 6144 waves of the grid hit the one head word at start-up: 70 us of
+    // serialised atomics (88 per us) before the last wave had anything to do — 0.07 of the kernel's 0.53 ms on the full frame,
+    // most of its 0.21 ms floor on small bands.
     const uint32_t nWaves = gridDim.x * (uint32_t)(kBlock / 64), myWave = blockIdx.x * (uint32_t)(kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t share = (total + nWaves - 1u) / nWaves;
-    const uint32_t chunk = share < q.chunk ? (share < 16u ? 16u : share) : q.chunk;
-    const uint32_t dynBase = nWaves * chunk;
+    const uint32_t share = (total + nWaves - 1u) / nWaves;        // an even share of the queue
+    const uint32_t chunk = q.chunk;                                // granularity of the dynamic part
+    const uint32_t want1 = chunk * q.staticChunks;                 // tasks a wave owns statically when there is plenty (tuning key 9 x chunk)
+    const uint32_t first = share < want1 ? (share < 16u ? 16u : share) : want1;
+    const uint32_t dynBase = nWaves * first;
     const bool hasDyn = dynBase < total;                           // otherwise the static chunks cover the whole queue: no atomics at all
     const bool counting = sc.rayCounter != nullptr;
     LaneRay r; r.cur = kExit; r.top = 0;
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     bool pending = false;                                          // lane's ray is finished, its pixel epilogue not yet run
     uint32_t outcome = 0;                                          // of the finished ray: 0 occluded, 1 light visible, 2 nothing hit (sky)
     bool more = total != 0u;                                       // wave-uniform: tasks may remain (in the queue or in this wave's chunk)
-    uint32_t chunkNext = myWave * chunk < total ? myWave * chunk : total;     // wave-uniform: this wave's claimed range of the queue
-    uint32_t chunkEnd = (myWave + 1u) * chunk < total ? (myWave + 1u) * chunk : total;
+    uint32_t chunkNext = myWave * first < total ? myWave * first : total;     // wave-uniform: this wave's claimed range of the queue
+    uint32_t chunkEnd = (myWave + 1u) * first < total ? (myWave + 1u) * first : total;
     while (true) {
         // ---------------- refill: idle lanes take the next tasks of the wave's chunk; a new chunk is stolen from the queue head when it runs dry
         const unsigned long long idle = __ballot(!active);

@@ -241,6 +241,8 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        scatter, no global atomics).  Default 0: measured +0.04 ms for the sort and no faster trace — shadow-ray cost is
  *        dominated by the geometry around the ray ORIGIN, which the unsorted tile order already keeps coherent.
  * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
+ * key 9: chunks every persistent wave owns statically before it starts stealing from the shared head (default 1; on
+ *        queues shorter than the grid the static part is an even share and no atomic is issued at all).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
  * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
  *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).

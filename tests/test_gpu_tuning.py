@@ -1,5 +1,5 @@
 """Every result-neutral tuning knob (fyprt_set_tuning) must leave every output bit unchanged: tile order, fused vs
-wavefront Part 2, persistent grid size, light-sorted task order, chunk size, refill threshold, node-loop quorum."""
+wavefront Part 2, persistent grid size, light-sorted task order, chunk size, static chunks, refill threshold, node-loop quorum."""
 import numpy as np
 import pytest
 
@@ -14,6 +14,8 @@ VARIANTS = [
     {1: 0},                                         # Part 2 fused in one kernel
     {1: 0, 6: 0},                                   # ... with the classic while-while loop
     {2: 2}, {4: 32, 5: 8}, {4: 256, 5: 48},         # persistent grid / chunk / refill
+    {2: 1, 4: 16, 5: 8}, {2: 1, 4: 16, 9: 3},       # small grid + small chunks: the queue is longer than the static chunks -> dynamic stealing runs
+    {9: 4},                                         # statically owned chunks per wave
     {3: 1},                                         # shadow tasks sorted by light bin
     {6: 0}, {6: 40}, {7: 16},                       # node-loop quorum (shadow rays / every other kernel)
 ]
