@@ -60,7 +60,7 @@ struct fyprt_context {
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[10] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[11] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
@@ -399,7 +399,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
                 ShadowQueue q{};
                 q.tasks = c->shadowTasks.p; q.counters = c->queueCounters.p;
-                q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24); q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1);
+                q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24); q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
                 q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p; q.keys = c->sortKeys.p; q.hist = c->sortHist.p;
                 q.binOffset = c->sortOffset.p; q.binTotal = c->sortTotal.p; q.sorted = c->sortIndex.p;
                 HIPCHK(c, hipMemsetAsync(c->queueCounters.p, 0, 16, c->stream));
@@ -567,13 +567,13 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 10) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 11) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : c->tuning[key];
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 10) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 11) return FYPRT_EINVAL;
     c->tuning[key] = value;
     return FYPRT_OK;
 }

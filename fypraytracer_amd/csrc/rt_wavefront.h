@@ -18,7 +18,7 @@
 namespace rt {
 
 struct ShadowQueue {
-    float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes, staticChunks;
+    float4* tasks; uint32_t* counters; uint32_t chunk, refillLanes, staticChunks, minChunk;
     // light-sorted mode (tuning key 3): tasks are slotted per setup workgroup, a counting sort over kSortBins light bins
     // produces `sorted` (task slots in bin order) without a single global atomic
     uint32_t sortMode, numGroups; uint32_t* counts; uint8_t* keys; uint16_t* hist; uint32_t* binOffset; uint32_t* binTotal; uint32_t* sorted;
@@ -207,10 +207,15 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
         if (more && (uint32_t)__popcll(idle) >= q.refillLanes) {
             if (chunkNext >= chunkEnd && hasDyn) {
                 uint32_t base = 0;
-                if (lane == 0u) base = dynBase + atomicAdd(q.counters + 1, chunk);
+                // guided self-scheduling: full chunks while the queue is long, smaller ones towards its end (a 128-task chunk
+                // is ~150 us of work for a wave, a third of the kernel); the remaining length is taken from the wave's own
+                // previous claim, so no extra access to the head word is needed
+                uint32_t size = (total - chunkEnd) / nWaves;
+                size = size < q.minChunk ? q.minChunk : (size > chunk ? chunk : size);
+                if (lane == 0u) base = dynBase + atomicAdd(q.counters + 1, size);
                 base = (uint32_t)__shfl((int)base, 0);
                 chunkNext = base < total ? base : total;
-                chunkEnd = (base + chunk < total) ? base + chunk : total;
+                chunkEnd = (base + size < total) ? base + size : total;
             }
             const uint32_t slot = chunkNext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t want = (uint32_t)__popcll(idle), avail = chunkEnd - chunkNext;

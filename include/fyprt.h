@@ -243,6 +243,8 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
  * key 9: chunks every persistent wave owns statically before it starts stealing from the shared head (default 1; on
  *        queues shorter than the grid the static part is an even share and no atomic is issued at all).
+ * key 10: smallest chunk of the guided self-scheduling of the shared part: claims shrink from key 4 towards this value as
+ *        the queue runs out (default 32).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
  * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
  *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).

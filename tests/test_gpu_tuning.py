@@ -15,7 +15,7 @@ VARIANTS = [
     {1: 0, 6: 0},                                   # ... with the classic while-while loop
     {2: 2}, {4: 32, 5: 8}, {4: 256, 5: 48},         # persistent grid / chunk / refill
     {2: 1, 4: 16, 5: 8}, {2: 1, 4: 16, 9: 3},       # small grid + small chunks: the queue is longer than the static chunks -> dynamic stealing runs
-    {9: 4},                                         # statically owned chunks per wave
+    {9: 4}, {2: 1, 4: 64, 10: 16},                  # statically owned chunks per wave; guided claims down to 16 tasks
     {3: 1},                                         # shadow tasks sorted by light bin
     {6: 0}, {6: 40}, {7: 16},                       # node-loop quorum (shadow rays / every other kernel)
 ]
