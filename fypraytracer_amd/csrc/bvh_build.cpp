@@ -2,9 +2,9 @@
 // Binned SAH (16 bins, 3 axes) over triangle centroids, up to 4 triangles per leaf, two levels (a tree per mesh under a
 // tree over the meshes) merged into one binary tree, which is then collapsed into 4-wide nodes with 8-bit quantised child
 // boxes (one 64-byte fetch per four children), nodes in pre-order so the top of the tree is contiguous in memory.  Depth is bounded BY CONSTRUCTION: every
-// subtree gets a depth budget (kMaxDepth for the TLAS root, the remainder for each BLAS) and a node whose
+// subtree gets a depth budget (the bound for the TLAS root, the remainder for each BLAS) and a node whose
 // remaining budget is only just enough for a balanced subtree of its size is split at the object median
-// instead of the SAH plane, so leaf depth <= kMaxDepth and the kernels' 32-entry LDS stack never overflows.  This replaces the reference's recursive builder
+// instead of the SAH plane, so leaf depth stays bounded (see kMaxDepthRelaxed / kMaxDepthSafe below).  This replaces the reference's recursive builder
 // (BVH.cpp:146-309, one triangle per leaf, unordered) — the tree SHAPE is ours; the set of
 // triangles a ray can reach is the same, and the closest hit is found with the reference's
 // own Möller–Trumbore arithmetic, so results match except for exact-tie order.
@@ -29,14 +29,19 @@ struct Box {
 };
 struct Prim { Box b; float c[3]; uint32_t id; };
 
-constexpr uint32_t kMaxDepth = 30;   // leaf depth bound (kernel stack: kStackDepth = 32 >= kMaxDepth + 2)
+// Leaf depth bound of the binary tree.  What the kernels need is a WIDE tree of at most kStackBudget (31) levels (node_step's
+// stack rule); a wide level swallows about two binary ones, so the binary tree is first built with a generous bound (SAH
+// splits almost everywhere) and only if its collapse ends up deeper than 31 levels — pathological input — once more with the
+// bound that guarantees it (wide levels <= binary height <= 30).
+constexpr uint32_t kMaxDepthRelaxed = 48, kMaxDepthSafe = 30;
 inline uint32_t ceilLog2(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) ++l; return l; }
 
 // binary node of the intermediate SAH tree (both child boxes in the parent)
 struct Node2 { float lo0[3], hi0[3], lo1[3], hi1[3]; int32_t child0, child1; };
 
 struct Builder {
-    std::vector<Node2> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepth;
+    uint64_t forced = 0;
+    std::vector<Node2> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepthSafe;
     std::function<int32_t(const Prim*, uint32_t, uint32_t)> makeLeaf;   // (prims, count, depth) -> leaf ref
     static constexpr int kBins = 16;
 
@@ -49,6 +54,7 @@ struct Builder {
         // leaves needed below this node if split evenly from here on: ceil(count / maxLeaf) -> levels = ceilLog2(that)
         const uint32_t balancedLevels = ceilLog2((count + maxLeaf - 1) / maxLeaf);
         const bool mustBalance = depth + balancedLevels + 1 >= depthLimit;
+        if (mustBalance && count > maxLeaf) ++forced;
         if (count > 1 && !mustBalance) {
             for (int axis = 0; axis < 3; ++axis) {
                 const float cmin = cb.lo[axis], cmax = cb.hi[axis];
@@ -107,7 +113,7 @@ struct Builder {
 // summed surface area of the wide nodes (below).  Every node records how many wide levels its subtree has: the traversal
 // pushes the siblings it does not visit next one by one while  pending + 2 + levels <= kStackBudget  and otherwise a
 // single "resume this node" entry (rt_device.h: node_step), so the pending-entry count can never exceed
-// kStackBudget as long as the tree has at most kStackBudget levels — which the binary depth bound (kMaxDepth) implies.
+// kStackBudget as long as the tree has at most kStackBudget levels — which BuildSceneBVH guarantees.
 struct Collapser {
     const std::vector<Node2>& bn; std::vector<uint8_t> height; std::vector<Node> out;
     // SAH-optimal collapse (dynamic programme over the binary tree): cost[n][j-1] = least sum of wide-node surface areas that
@@ -204,10 +210,10 @@ inline const uint32_t* triIdx(const uint8_t* tris, uint32_t stride, uint32_t i) 
 
 }  // namespace
 
-void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
-                   uint32_t meshCount, SceneBVH& out) {
+static void BuildWithDepthBound(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
+                               uint32_t meshCount, uint32_t kMaxDepth, SceneBVH& out) {
     out = SceneBVH();
-    struct MeshOut { std::vector<Node2> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
+    struct MeshOut { uint64_t forced = 0; std::vector<Node2> nodes; std::vector<Tri> tris; int32_t root = 0; uint32_t depth = 0; Box box; bool valid = false; };
     std::vector<MeshOut> mo(meshCount);
     // mesh bounds first: the TLAS only needs them, and its leaf depths set each BLAS's depth budget
     for (uint32_t m = 0; m < meshCount; ++m) {
@@ -257,7 +263,7 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
         };
         Box bb;
         o.root = b.build(prims.data(), 0, (uint32_t)prims.size(), 0, bb);
-        o.nodes.swap(b.nodes); o.depth = b.maxDepth;
+        o.nodes.swap(b.nodes); o.depth = b.maxDepth; o.forced = b.forced;
     }
     // merge into one binary tree (TLAS nodes first, then each BLAS), relocating child references
     const uint32_t tlasNodes = (uint32_t)tb.nodes.size();
@@ -291,8 +297,15 @@ void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triS
     uint32_t levels = 0;
     out.rootRef = col.emit(binRoot, levels);
     out.levels = levels;
+    if (std::getenv("FYPRT_BVH_DEBUG")) { uint64_t f = tb.forced; uint32_t big = 0; for (uint32_t m = 0; m < meshCount; ++m) { f += mo[m].forced; big = std::max(big, meshes[m].triangle_count); } std::fprintf(stderr, "[bvh] forced median splits %llu, TLAS forced %llu, largest mesh %u tris\n", (unsigned long long)f, (unsigned long long)tb.forced, big); }
     if (std::getenv("FYPRT_BVH_DEBUG")) std::fprintf(stderr, "[bvh] binary nodes %zu height %u, wide nodes %zu, wide levels %u, tris %zu\n", bin.size(), col.h(binRoot), col.out.size(), levels, out.tris.size());
     out.nodes.swap(col.out);
+}
+
+void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
+                   uint32_t meshCount, SceneBVH& out) {
+    BuildWithDepthBound(verts, tris, triStride, meshes, meshCount, kMaxDepthRelaxed, out);
+    if (out.levels > kStackBudget || std::getenv("FYPRT_BVH_FORCE_SAFE_DEPTH")) BuildWithDepthBound(verts, tris, triStride, meshes, meshCount, kMaxDepthSafe, out);
 }
 
 }  // namespace rth

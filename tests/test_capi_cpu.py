@@ -121,28 +121,60 @@ def test_bvh_invariants(name):
     ctx.close()
 
 
-def test_bvh_depth_is_bounded_by_construction():
-    """Pathological input for SAH (a long chain of ever smaller, nested triangles all sharing a corner): the builder
-    must fall back to median splits early enough that depth + 2 <= 32 (the kernels have no stack spill path)."""
+def _one_mesh_scene(pos):
     from fypraytracer_amd.scene import Material, Scene
-    n = 6000
-    k = np.arange(n, dtype=np.float64)
-    s = 0.999 ** k
-    pos = np.zeros((n * 3, 3), dtype=np.float32)
-    pos[0::3] = 0.0
-    pos[1::3, 0] = s
-    pos[2::3, 1] = s
-    nrm = np.tile(np.array([0, 0, 1], dtype=np.float32), (n * 3, 1))
-    uv = np.zeros((n * 3, 2), dtype=np.float32)
-    idx = np.arange(n * 3, dtype=np.uint32).reshape(-1, 3)
+    n = len(pos) // 3
     sc = Scene()
     sc.materials = [Material(albedo=(1, 1, 1))]
-    sc.add_new_mesh_to_scene(pos, nrm, uv, idx, material_index=0)
+    sc.add_new_mesh_to_scene(pos, np.tile(np.array([0, 0, 1], dtype=np.float32), (n * 3, 1)), np.zeros((n * 3, 2), dtype=np.float32),
+                             np.arange(n * 3, dtype=np.uint32).reshape(-1, 3), material_index=0)
+    return sc
+
+
+def _tree_levels(b):
+    nodes = b["nodes"]
+
+    def lv(ref):
+        if ref < 0:
+            return 0
+        n = nodes[ref]
+        return 1 + max(lv(int(c)) for c in n["child"][:int(n["meta"]) & 7])
+    return lv(b["root"])
+
+
+@pytest.mark.parametrize("force_safe", [False, True])
+@pytest.mark.parametrize("shape", ["nested", "exponential"])
+def test_bvh_depth_is_bounded_by_construction(shape, force_safe, monkeypatch):
+    """Pathological inputs for SAH — a long chain of ever smaller nested triangles sharing a corner, and triangles at
+    exponentially shrinking distances (every split peels off a handful) — must still give a tree of <= 31 wide levels: the
+    binary builder falls back to median splits when its depth budget runs out, first under a generous bound (48), and the
+    whole build is repeated under the bound that guarantees it (30) should the collapse still be too deep; `force_safe`
+    runs that second build unconditionally."""
+    if force_safe:
+        monkeypatch.setenv("FYPRT_BVH_FORCE_SAFE_DEPTH", "1")
+    if shape == "nested":
+        n = 6000
+        s = 0.999 ** np.arange(n, dtype=np.float64)
+        pos = np.zeros((n * 3, 3), dtype=np.float32)
+        pos[1::3, 0] = s
+        pos[2::3, 1] = s
+    else:
+        n = 480
+        x = (2.0 ** -(np.arange(n, dtype=np.float64) * 0.25)).astype(np.float32)
+        pos = np.zeros((n * 3, 3), dtype=np.float32)
+        pos[0::3, 0] = x
+        pos[1::3, 0] = x * 1.01
+        pos[2::3, 0] = x
+        pos[2::3, 1] = x * 0.01
+    sc = _one_mesh_scene(pos)
     ctx = capi.Context(-1)
     ctx.upload_scene(sc)
     b = ctx.export_bvh()
-    assert b["max_stack"] <= 31
+    assert b["max_stack"] <= 31 and _tree_levels(b) == b["max_stack"]
+    if force_safe:
+        assert b["max_stack"] <= 30
     assert sorted(b["tris"]["tri"].tolist()) == list(range(n))
+    assert ctx.get_tuning(8) >= b["max_stack"]                                # the stack budget never undercuts the level count
     ctx.close()
 
 
