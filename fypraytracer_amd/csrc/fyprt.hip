@@ -75,11 +75,17 @@ struct fyprt_context {
 
 #define HIPCHK(ctx, call) do { int _rc = (ctx)->hip((call), #call); if (_rc != FYPRT_OK) return _rc; } while (0)
 
-// Effective pending-entry budget of node_step's stack rule for the uploaded tree: tuning key 8 if set, else a few entries
-// above the tree's level count; never below the level count (the induction needs it), never above kStackBudget.
+// Effective pending-entry budget of node_step's stack rule for the uploaded tree: tuning key 8 if set; otherwise a few entries
+// above the tree's level count, rounded DOWN to a stack size at which one more 256-thread workgroup fits the CU's 160 KB of
+// LDS (entries x 1 KB per workgroup: 32 -> 5 workgroups, 26 -> 6, 22 -> 7, 20 -> 8, 17 -> 9, 16 -> 10) as long as at least 4
+// entries of slack above the level count remain.  Never below the level count (the induction needs it), never above 31.
 static int effective_stack_budget(const fyprt_context* c) {
     const int levels = (int)c->hostBvh.levels;
-    return std::min((int)rth::kStackBudget, std::max(levels, c->tuning[8] > 0 ? c->tuning[8] : std::max(levels + 8, 19)));
+    if (c->tuning[8] > 0) return std::min((int)rth::kStackBudget, std::max(levels, c->tuning[8]));
+    static const int kSizes[6] = {16, 17, 20, 22, 26, 32};
+    int entries = 32;
+    for (int i = 5; i >= 0; --i) if (kSizes[i] <= std::max(levels + 9, 16) && kSizes[i] - 1 >= levels + 4) { entries = kSizes[i]; break; }
+    return std::min((int)rth::kStackBudget, std::max(levels, entries - 1));
 }
 
 extern "C" {

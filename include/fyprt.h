@@ -249,8 +249,9 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
  *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).
  * key 7: the same for every other kernel (default 0: measured neutral or slightly negative there).
- * key 8: pending-entry budget of the traversal stack rule (default 0 = tree levels + 8, at least 19; at most 31; always
- *        clamped from below to the tree's level count): siblings are pushed one by one while
+ * key 8: pending-entry budget of the traversal stack rule (default 0 = a few entries above the tree's level count, chosen
+ *        so that one more workgroup fits a CU's LDS; at most 31; always clamped from below to the tree's level count):
+ *        siblings are pushed one by one while
  *        pending + 2 + levels(node) <= budget, else as one resume entry; the LDS stack holds budget + 1 entries per thread.
  *        Unlike keys 0-7 the value can change the visiting order (exact-t ties may resolve differently). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
