@@ -386,18 +386,16 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
         case FYPRT_RESTIR_DI: case FYPRT_RESTIR_GI: {
             const uint32_t p1b = (c->rowBegin > c->halo) ? c->rowBegin - c->halo : 0u;
             const uint32_t p1e = (c->rowEnd + c->halo < c->H) ? c->rowEnd + c->halo : c->H;
-            const dim3 g1 = gridFor(p1b, p1e);
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // Part 1 traces coherent primary rays only
-            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
-            else hipLaunchKernelGGL(k_gi_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e);
             // The reference's spatial-neighbour coordinate is computed in unsigned arithmetic (R.cu:1916-1917): an offset
             // above the first row wraps and clamps to the LAST row.  A band that owns rows < radius therefore also needs
-            // Part 1 of row H-1 (one extra row of recompute) to stay bit-identical to a single-GPU frame.
-            if (c->halo > 0 && c->rowBegin < c->halo && p1e < c->H) {
-                const dim3 g2 = gridFor(c->H - 1u, c->H);
-                if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g2, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
-                else hipLaunchKernelGGL(k_gi_part1, g2, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->H - 1u, c->H);
-            }
+            // Part 1 of row H-1 (one extra row of recompute) to stay bit-identical to a single-GPU frame.  It rides in the same
+            // launch as one more row of tiles (a separate one-row launch is all latency: ~0.09 ms on a 135-row band).
+            const bool extra = c->halo > 0 && c->rowBegin < c->halo && p1e < c->H;
+            const uint32_t extraRow = extra ? c->H - 1u : 0xFFFFFFFFu;
+            const dim3 g1 = gridFor(p1b, extra ? p1e + 16u : p1e);
+            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+            else hipLaunchKernelGGL(k_gi_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
             if (tech == FYPRT_RESTIR_DI) c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
@@ -574,7 +572,7 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
     if (!c || !value || key < 0 || key >= 11) return FYPRT_EINVAL;
-    *value = (key == 8) ? effective_stack_budget(c) : c->tuning[key];
+    *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 

@@ -38,6 +38,17 @@ RT_DEV bool pixel_of_thread(const DevFrame& fr, uint32_t rowBegin, uint32_t rowE
     return x < fr.W && y < rowEnd;
 }
 
+// Part 1 of ReSTIR: rows [p1Begin, p1End) plus, for a top band of a multi-GPU split, the single row `extraRow` (mapped to the
+// first row of one more row of tiles; 0xFFFFFFFF = none)
+RT_DEV bool p1_pixel_of_thread(const DevFrame& fr, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow, uint32_t& x, uint32_t& y) {
+    if (extraRow == 0xFFFFFFFFu) return pixel_of_thread(fr, p1Begin, p1End, x, y);
+    if (!pixel_of_thread(fr, p1Begin, p1End + 16u, x, y)) return false;
+    if (y < p1End) return true;
+    if (y != ((p1End - p1Begin + 15u) & ~15u) + p1Begin) return false;      // only the first row of the extra tile row
+    y = extraRow;
+    return true;
+}
+
 // Common epilogue of all 11 reference kernels (e.g. Renderer.cu:2448-2465)
 RT_DEV void epilogue(const DevFrame& fr, uint32_t i, f4 c) {
     if (!(finitef(c.x) && finitef(c.y) && finitef(c.z) && finitef(c.w))) c = mk4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -360,10 +371,10 @@ RT_DEV uint32_t neighbor_index(const DevCamera& cam, uint32_t W, uint32_t x, uin
 
 // Part 1 rows: [p1Begin, p1End) (band + halo); finished pixels (sky / emitter) go through the
 // epilogue only inside the band proper so halo rows never touch accumulation.
-__global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End) {
+__global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
-    if (!pixel_of_thread(fr, p1Begin, p1End, x, y)) return;
+    if (!p1_pixel_of_thread(fr, p1Begin, p1End, extraRow, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
     const uint32_t i = x + y * fr.W;
     const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
@@ -491,10 +502,10 @@ RT_DEV void gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {     
 }
 RT_DEV f3 lo3(const GISample& s) { return mk3(s.Lo[0], s.Lo[1], s.Lo[2]); }
 
-__global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End) {
+__global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
-    if (!pixel_of_thread(fr, p1Begin, p1End, x, y)) return;
+    if (!p1_pixel_of_thread(fr, p1Begin, p1End, extraRow, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
     const uint32_t i = x + y * fr.W;
     const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
