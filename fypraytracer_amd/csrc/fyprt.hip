@@ -43,6 +43,9 @@ void matmul_cm(const float* a, const float* b, float* out) {
 
 struct fyprt_context {
     int device = 0; hipStream_t stream = nullptr; std::string err; bool hostOnly = false;
+    // ReSTIR DI frames are pipelined over two streams: Part 1 + Part-2 setup of frame N+1 (front stream) run beside the
+    // persistent trace kernel of frame N (`stream`, on which every frame COMPLETES and which fyprt_stream() hands out)
+    hipStream_t front = nullptr; hipEvent_t evFront[2] = {}, evDone[2] = {}; bool lastOverlapped = false; bool ringSplit[128] = {};
     static constexpr int kRing = 128;          // frames whose per-launch hipEvents are kept (fyprt_frame_timings)
     hipEvent_t ring[kRing][5] = {}; int ringLaunches[kRing] = {}; unsigned long long frameSerial = 0; hipEvent_t* ev = nullptr;
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
@@ -59,8 +62,9 @@ struct fyprt_context {
     DevScene dsc{}; DevCamera dcam{};
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
+    size_t queueStride = 0;                     // float4s per task queue
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[11] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[12] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
@@ -74,6 +78,12 @@ struct fyprt_context {
 };
 
 #define HIPCHK(ctx, call) do { int _rc = (ctx)->hip((call), #call); if (_rc != FYPRT_OK) return _rc; } while (0)
+
+static hipError_t sync_all(fyprt_context* c) {      // both streams: the front one only ever runs ahead of `stream`
+    hipError_t e = c->front ? hipStreamSynchronize(c->front) : hipSuccess;
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    return e != hipSuccess ? e : e2;
+}
 
 // Effective pending-entry budget of node_step's stack rule for the uploaded tree: tuning key 8 if set; otherwise a few entries
 // above the tree's level count, rounded DOWN to a stack size at which one more 256-thread workgroup fits the CU's 160 KB of
@@ -107,9 +117,12 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     auto* c = new fyprt_context(); c->device = device_ordinal;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
+    e = hipStreamCreateWithFlags(&c->front, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) { e = hipEventCreateWithFlags(&c->evFront[k], hipEventDisableTiming); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming); }
+    if (e != hipSuccess) { g_createError = std::string("front stream / events: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
     for (auto& row : c->ring) for (auto& e : row) (void)hipEventCreate(&e);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
-    (void)c->queueCounters.alloc(4);
+    (void)c->queueCounters.alloc(8);          // two queues (frame parity): tail, head, pad, pad each
     (void)c->rayCounter.alloc(16);
     (void)hipMemset(c->rayCounter.p, 0, 128);
     *out = c;
@@ -120,7 +133,7 @@ void fyprt_destroy(fyprt_context* c) {
     if (!c) return;
     if (c->hostOnly) { delete c; return; }
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     c->accum.release(); c->image.release(); c->payload.release(); c->depth.release(); c->normalA.release(); c->normalB.release();
     c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release(); c->drec.release(); c->dprevA.release(); c->dprevB.release();
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
@@ -129,6 +142,8 @@ void fyprt_destroy(fyprt_context* c) {
     c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
     c->sortCounts.release(); c->sortOffset.release(); c->sortTotal.release(); c->sortIndex.release(); c->sortKeys.release(); c->sortHist.release();
     for (auto& row : c->ring) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) { if (c->evFront[k]) (void)hipEventDestroy(c->evFront[k]); if (c->evDone[k]) (void)hipEventDestroy(c->evDone[k]); }
+    if (c->front) (void)hipStreamDestroy(c->front);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -140,7 +155,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 31)) return c->fail(FYPRT_EINVAL, "fyprt_resize: bad size");
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context (device -1) has no device buffers");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     const size_t n = (size_t)w * h;
     HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
     HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
@@ -151,7 +166,8 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     {   // shadow-task storage: 256 slots per setup workgroup (grid padded to whole groups of 8 tile rows), + the sort scratch
         const size_t tilesX = (w + 15u) / 16u, tilesY = (h + 15u) / 16u;
         const size_t maxGroups = std::max(tilesX * ((tilesY + 7u) / 8u) * 8u, ((tilesX * tilesY + 7u) / 8u) * 8u);
-        HIPCHK(c, c->shadowTasks.alloc(maxGroups * 256u * 4u));
+        HIPCHK(c, c->shadowTasks.alloc((size_t)maxGroups * 256u * 4u * 2u));   // two queues (frame parity) of 64-byte tasks
+        c->queueStride = (size_t)maxGroups * 256u * 4u;
         HIPCHK(c, c->sortCounts.alloc(maxGroups)); HIPCHK(c, c->sortKeys.alloc(maxGroups * 256u)); HIPCHK(c, c->sortHist.alloc(maxGroups * kSortBins));
         HIPCHK(c, c->sortOffset.alloc(maxGroups * kSortBins)); HIPCHK(c, c->sortTotal.alloc(kSortBins)); HIPCHK(c, c->sortIndex.alloc(maxGroups * 256u));
     }
@@ -161,7 +177,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemsetAsync(c->normalA.p, 0, c->normalA.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->normalB.p, 0, c->normalB.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->di.p, 0, c->di.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->diPrev.p, 0, c->diPrev.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->gi.p, 0, c->gi.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->giPrev.p, 0, c->giPrev.bytes(), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->externalImage = nullptr;
     if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
     return FYPRT_OK;
@@ -185,7 +201,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     if ((s->triangle_count && (!s->triangles || !s->vertices || s->triangle_stride < 16)) || (s->mesh_count && !s->meshes) ||
         (s->material_count && !s->materials))
         return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: NULL array with non-zero count");
-    if (!c->hostOnly) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    if (!c->hostOnly) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c)); }
     const uint8_t* tb = (const uint8_t*)s->triangles;
     auto tri = [&](uint32_t i) { return reinterpret_cast<const uint32_t*>(tb + (size_t)i * s->triangle_stride); };
     for (uint32_t i = 0; i < s->triangle_count; ++i) {
@@ -310,7 +326,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     if (!c->hostOnly && !em.empty()) {
         hipLaunchKernelGGL(k_build_light_records, dim3(((uint32_t)em.size() + 255u) / 256u), dim3(256), 0, c->stream, d, c->lightRecs.p);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_all(c));
     }
     c->haveScene = true;
     return FYPRT_OK;
@@ -359,11 +375,25 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     const int budget = effective_stack_budget(c);
     c->dsc.stackBudget = budget;
     const size_t ldsBytes = (size_t)(budget + 1) * kBlock * sizeof(int32_t);
+    // Pipelining (tuning key 11): a wavefront ReSTIR DI frame runs Part 1 + setup on the front stream and the trace kernel on
+    // `stream`.  Nothing the front part writes is read or written by a trace kernel (payload, records, history, depth, its own
+    // task queue — two queues alternate), and image + accumulation are touched by trace kernels only (p1Mode 1), which stay in
+    // frame order on `stream`; so frame N+1's front part may run beside frame N's trace kernel.  Any other frame runs on
+    // `stream` alone, after everything before it.
+    const int par = (int)(c->frameSerial & 1ull);
+    const bool wavefront = tech == FYPRT_RESTIR_DI && c->tuning[1] == 1;
+    const bool overlap = wavefront && c->tuning[11] != 0 && !c->countRays;
+    hipStream_t fs = overlap ? c->front : c->stream;             // where Part 1 + setup go
+    if (overlap) {
+        HIPCHK(c, hipStreamWaitEvent(c->front, c->evDone[par], 0));                            // frame N-2 done: its queue is free
+        if (!c->lastOverlapped) HIPCHK(c, hipStreamWaitEvent(c->front, c->evDone[par ^ 1], 0));   // frame N-1 ran on `stream` alone
+    }
     if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
-    // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51)
+    // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51) — on `stream`, which owns it
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
     fr.tileOrder = (uint32_t)c->tuning[0];
+    fr.p1Mode = wavefront ? 1u : 0u;
     auto gridFor = [&](uint32_t rb, uint32_t re) {
         const uint32_t tilesY = (re - rb + 15u) / 16u;
         if (c->tuning[0] == 2) return dim3(tilesX * ((tilesY + 7u) / 8u) * 8u);
@@ -373,7 +403,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     const dim3 grid = gridFor(c->rowBegin, c->rowEnd);
     int ei = 0;
     c->ev = c->ring[c->frameSerial % fyprt_context::kRing];
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
     int launches = 0;
     switch (tech) {
         case FYPRT_BRUTE_FORCE: hipLaunchKernelGGL(k_path<T_BRUTE>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
@@ -394,25 +424,30 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             const bool extra = c->halo > 0 && c->rowBegin < c->halo && p1e < c->H;
             const uint32_t extraRow = extra ? c->H - 1u : 0xFFFFFFFFu;
             const dim3 g1 = gridFor(p1b, extra ? p1e + 16u : p1e);
-            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
             else hipLaunchKernelGGL(k_gi_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
             if (tech == FYPRT_RESTIR_DI) c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
-            if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+            if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
             launches = 2;
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
                 ShadowQueue q{};
-                q.tasks = c->shadowTasks.p; q.counters = c->queueCounters.p;
+                q.tasks = c->shadowTasks.p + (size_t)par * c->queueStride; q.counters = c->queueCounters.p + 4 * par;
                 q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24); q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
                 q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p; q.keys = c->sortKeys.p; q.hist = c->sortHist.p;
                 q.binOffset = c->sortOffset.p; q.binTotal = c->sortTotal.p; q.sorted = c->sortIndex.p;
-                HIPCHK(c, hipMemsetAsync(c->queueCounters.p, 0, 16, c->stream));
-                hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, c->stream, c->dsc, c->dcam, fr, st, q);
+                HIPCHK(c, hipMemsetAsync(q.counters, 0, 16, fs));
+                hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, fs, c->dsc, c->dcam, fr, st, q);
                 if (q.sortMode) {
-                    hipLaunchKernelGGL(k_di_sort_scan, dim3(kSortBins), block, 0, c->stream, q);
-                    hipLaunchKernelGGL(k_di_sort_scatter, grid, block, 0, c->stream, q);
+                    hipLaunchKernelGGL(k_di_sort_scan, dim3(kSortBins), block, 0, fs, q);
+                    hipLaunchKernelGGL(k_di_sort_scatter, grid, block, 0, fs, q);
                 }
-                if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+                if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
+                if (overlap) {                                   // the trace kernel waits for this frame's front part only
+                    HIPCHK(c, hipEventRecord(c->evFront[par], c->front));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evFront[par], 0));
+                    if (timed) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));      // start of the trace kernel on its own stream
+                }
                 if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;
                 int perCU = c->tuning[2];
                 if (perCU <= 0) {          // as many workgroups as registers + LDS let a CU hold (asked from the runtime once per stack size)
@@ -434,8 +469,11 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     }
     HIPCHK(c, hipGetLastError());
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+    HIPCHK(c, hipEventRecord(c->evDone[par], c->stream));                // the frame is complete (and its task queue free again)
+    c->lastOverlapped = overlap;
     c->lastLaunches = launches; c->lastTech = tech;
     c->ringLaunches[c->frameSerial % fyprt_context::kRing] = timed ? launches : 0;
+    c->ringSplit[c->frameSerial % fyprt_context::kRing] = overlap;
     c->frameSerial++;
     if (s->to_accumulate) c->frameIndex++; else c->frameIndex = 1;       // Renderer.cu:258-261
     return FYPRT_OK;
@@ -445,12 +483,16 @@ int fyprt_render(fyprt_context* c, const fyprt_settings* s, fyprt_frame_stats* s
     if (!c || !s) return FYPRT_EINVAL;
     int rc = enqueue_frame(c, s, true);
     if (rc != FYPRT_OK) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));                            // cudaDeviceSynchronize, Renderer.cu:237
+    HIPCHK(c, sync_all(c));                            // cudaDeviceSynchronize, Renderer.cu:237
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->launches = (uint32_t)c->lastLaunches;
         float total = 0.0f;
-        for (int k = 0; k < c->lastLaunches; ++k) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]); stats->kernel_ms_part[k] = ms; total += ms; }
+        const bool split = c->ringSplit[(c->frameSerial - 1ull) % fyprt_context::kRing];
+        for (int k = 0; k < c->lastLaunches; ++k) {
+            float ms = 0.0f; (void)hipEventElapsedTime(&ms, (split && k == 2) ? c->ev[4] : c->ev[k], c->ev[k + 1]);   // split frame: the trace kernel has its own start event
+            stats->kernel_ms_part[k] = ms; total += ms;
+        }
         stats->kernel_ms = total;
         if (c->countRays) {
             unsigned long long r[16] = {0}; (void)hipMemcpy(r, c->rayCounter.p, 128, hipMemcpyDeviceToHost);
@@ -473,20 +515,20 @@ int fyprt_frame_timings(fyprt_context* c, uint32_t frames_back, float* kernel_ms
     for (int k = 0; k < 4; ++k) kernel_ms_part4[k] = 0.0f;
     for (int k = 0; k < n && k < 4; ++k) {
         float ms = 0.0f;
-        hipError_t e = hipEventElapsedTime(&ms, c->ring[slot][k], c->ring[slot][k + 1]);
+        hipError_t e = hipEventElapsedTime(&ms, (c->ringSplit[slot] && k == 2) ? c->ring[slot][4] : c->ring[slot][k], c->ring[slot][k + 1]);
         if (e != hipSuccess) return c->hip(e, "hipEventElapsedTime (synchronize the context first)");
         kernel_ms_part4[k] = ms;
     }
     if (launches) *launches = (uint32_t)n;
     return FYPRT_OK;
 }
-int fyprt_synchronize(fyprt_context* c) { if (!c) return FYPRT_EINVAL; if (c->hostOnly) return FYPRT_OK; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return FYPRT_OK; }
+int fyprt_synchronize(fyprt_context* c) { if (!c) return FYPRT_EINVAL; if (c->hostOnly) return FYPRT_OK; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c)); return FYPRT_OK; }
 
 int fyprt_readback(fyprt_context* c, uint32_t* rgba8, float* accum4) {
     if (!c) return FYPRT_EINVAL;
     if (c->hostOnly || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_readback before fyprt_resize");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     const size_t off = (size_t)c->rowBegin * c->W, cnt = (size_t)(c->rowEnd - c->rowBegin) * c->W;
     const uint32_t* img = c->externalImage ? c->externalImage : c->image.p;
     if (rgba8) HIPCHK(c, hipMemcpy(rgba8 + off, img + off, cnt * 4, hipMemcpyDeviceToHost));
@@ -502,7 +544,7 @@ int fyprt_read_buffer(fyprt_context* c, int which, void* dst, size_t bytes) {
     if (!c || !dst) return FYPRT_EINVAL;
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context has no device buffers");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     const void* src = nullptr; size_t n = 0;
     switch (which) {
         case FYPRT_BUF_ACCUM: src = c->accum.p; n = c->accum.bytes(); break;
@@ -571,13 +613,13 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 11) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 12) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 11) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 12) return FYPRT_EINVAL;
     c->tuning[key] = value;
     return FYPRT_OK;
 }

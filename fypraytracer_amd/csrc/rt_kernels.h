@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
         // reference never writes di_prev_reservoirs for pixels finished in Part 1)
         store_rec(fr.dprevWrite + i, pp.hitDistance, ncur, rec_reservoir(load_rec(fr.dprevRead + i)));
         fr.depth[i] = pp.hitDistance;
-        if (inBand) epilogue(fr, i, rgb1(finalColor));
+        if (inBand && fr.p1Mode == 0u) epilogue(fr, i, rgb1(finalColor));
         return;
     }
     const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
         }
     }
     store_rec(fr.drec + i, pp.hitDistance, ncur, R);
-    if (inBand) fr.image[i] = 0u;     // sentinel: ConvertToRGBA(vec4(0)) (Renderer.cu:2746-2750)
+    if (inBand && fr.p1Mode == 0u) fr.image[i] = 0u;     // sentinel: ConvertToRGBA(vec4(0)) (Renderer.cu:2746-2750)
 }
 
 __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {

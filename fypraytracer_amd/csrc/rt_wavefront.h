@@ -23,6 +23,7 @@ struct ShadowQueue {
     // produces `sorted` (task slots in bin order) without a single global atomic
     uint32_t sortMode, numGroups; uint32_t* counts; uint8_t* keys; uint16_t* hist; uint32_t* binOffset; uint32_t* binTotal; uint32_t* sorted;
 };
+constexpr uint32_t kNoRayTask = 0xFFFFFFFFu;   // light-triangle field of a task that carries only a finished pixel's colour
 constexpr uint32_t kSortBins = 64;   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
 constexpr int kRefillLanes = 16;
 
@@ -30,14 +31,25 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
     uint32_t x, y;
     const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
     const uint32_t i = x + y * fr.W;
-    bool live = inside && fr.image[i] == 0u;                          // Renderer.cu:2787
-    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = 0, lightSlot = 0;
+    // Which pixels continue into Part 2 is the reference's sentinel test (Renderer.cu:2787) — here derived from the payload
+    // with Part 1's own expressions instead of read back from the image: a pixel that saw the sky or an emitter is finished
+    // (R.cu:1650-1668) and becomes a task WITHOUT a ray that only carries its colour to the epilogue, so that Part 1 writes
+    // neither image nor accumulation and every epilogue of the frame runs in one place (the trace kernel).
+    bool live = false, noRay = false;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = kNoRayTask, lightSlot = 0;
+    Payload pp; Mat hm;
+    if (inside) {
+        pp = fr.payload[i];
+        if (pp.hitDistance < 0.0f) { noRay = true; Lvis = st.sky; }
+        else {
+            hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+            if (length(emission(hm)) > 0.0f) { noRay = true; Lvis = emission(hm); } else live = true;
+        }
+    }
     if (live) {
         uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
         const DIRec own = load_rec(fr.drec + i);
         DIRes R = rec_reservoir(own);
-        const Payload pp = fr.payload[i];
-        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
         const f3 pd = ray_direction(cam, x, y);
         if (st.useSpatial) {
             uint32_t Z = 0; DIRes S = di_empty();
@@ -83,7 +95,8 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
     __shared__ uint32_t s_count[kBlock / 64];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_hist[kSortBins];
-    const unsigned long long mask = __ballot(live);
+    const bool queued = live || noRay;
+    const unsigned long long mask = __ballot(queued);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0u) s_count[wave] = (uint32_t)__popcll(mask);
     if (q.sortMode && threadIdx.x < kSortBins) s_hist[threadIdx.x] = 0u;
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         // slotted storage (256 slots per workgroup, no global atomic) + this workgroup's row of the light histogram
         slot = blockIdx.x * (uint32_t)kBlock + rank;
         const uint32_t key = (uint32_t)(((unsigned long long)lightSlot * kSortBins) / (sc.emissiveCount ? sc.emissiveCount : 1u));
-        if (live) { atomicAdd(&s_hist[key], 1u); q.keys[slot] = (uint8_t)key; }
+        if (queued) { atomicAdd(&s_hist[key], 1u); q.keys[slot] = (uint8_t)key; }
         __syncthreads();
         if (threadIdx.x < kSortBins) q.hist[(size_t)blockIdx.x * kSortBins + threadIdx.x] = (uint16_t)s_hist[threadIdx.x];
         if (threadIdx.x == 0u) q.counts[blockIdx.x] = nLive;
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         __syncthreads();
         slot = s_base + rank;
     }
-    if (live) {
+    if (queued) {
         float4* t = q.tasks + (size_t)slot * 4;
         t[0] = make_float4(ro.x, ro.y, ro.z, __int_as_float((int)i));
         t[1] = make_float4(rd.x, rd.y, rd.z, __int_as_float((int)ti));
@@ -227,6 +240,8 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 const float4 t0 = t[0], t1 = t[1];
                 r.o = mk3(t0.x, t0.y, t0.z);
                 r.d = mk3(t1.x, t1.y, t1.z); r.lightTri = (uint32_t)__float_as_int(t1.w);
+                if (r.lightTri == kNoRayTask) { pending = true; outcome = 1u; }          // a finished pixel: straight to the epilogue with its colour (t[2])
+                else {
                 r.pk = make_raypk(r.o, safe_inv(r.d.x), safe_inv(r.d.y), safe_inv(r.d.z));
                 // light triangle first (same Möller–Trumbore as trace_shadow)
                 float tL = -1.0f;
@@ -252,9 +267,10 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 r.top = 0; lane_push(lds, r.top, kExit);
                 r.cur = (sc.triCount == 0 || ray_not_finite(r.o, r.d)) ? kExit : sc.rootRef;   // (a non-finite ray also fails the light test above: closest mode, miss)
                 active = true;
+                }
             }
         }
-        if (__ballot(active) == 0ull) { if (!more) break; else continue; }
+        if (__ballot(active) == 0ull) { if (!more && __ballot(pending) == 0ull) break; else continue; }   // (tasks without a ray leave lanes pending but not active)
         // ---------------- traverse until enough lanes have finished to make a refill worthwhile
         while (true) {
             // inner nodes

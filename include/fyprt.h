@@ -243,6 +243,8 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
  * key 9: chunks every persistent wave owns statically before it starts stealing from the shared head (default 1; on
  *        queues shorter than the grid the static part is an even share and no atomic is issued at all).
+ * key 11: 1 (default) = wavefront ReSTIR DI frames are pipelined over two streams: Part 1 + setup of frame N+1 run beside the
+ *        trace kernel of frame N (asynchronous frames only overlap, of course; a blocking fyprt_render waits for its frame).
  * key 10: smallest chunk of the guided self-scheduling of the shared part: claims shrink from key 4 towards this value as
  *        the queue runs out (default 32).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).

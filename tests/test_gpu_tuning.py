@@ -15,7 +15,7 @@ VARIANTS = [
     {1: 0, 6: 0},                                   # ... with the classic while-while loop
     {2: 2}, {4: 32, 5: 8}, {4: 256, 5: 48},         # persistent grid / chunk / refill
     {2: 1, 4: 16, 5: 8}, {2: 1, 4: 16, 9: 3},       # small grid + small chunks: the queue is longer than the static chunks -> dynamic stealing runs
-    {9: 4}, {2: 1, 4: 64, 10: 16},                  # statically owned chunks per wave; guided claims down to 16 tasks
+    {9: 4}, {2: 1, 4: 64, 10: 16}, {11: 0},          # static chunks per wave; guided claims down to 16 tasks; no two-stream pipelining
     {3: 1},                                         # shadow tasks sorted by light bin
     {6: 0}, {6: 40}, {7: 16},                       # node-loop quorum (shadow rays / every other kernel)
 ]
@@ -71,3 +71,38 @@ def test_async_frames_equal_blocking_frames():
         outs.append(ctx.readback())
         ctx.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
+
+
+@pytest.mark.parametrize("pipelined", [1, 0])
+def test_pipelined_frames_with_technique_switches(pipelined):
+    """ReSTIR DI frames are pipelined over two streams (frame N+1's Part 1 + setup beside frame N's trace kernel, tuning key
+    11); frames of other techniques, instrumented frames and blocking frames in between must still see everything before them.
+    A long asynchronous sequence with technique switches and a frame-index reset equals the same sequence rendered blocking."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 208, 120
+    cam = mk_cam(W, H)
+    seq = [capi.RESTIR_DI] * 5 + [capi.RESTIR_GI, capi.RESTIR_DI, capi.RESTIR_DI, capi.COSINE_WEIGHTED_SAMPLING] + [capi.RESTIR_DI] * 4
+    outs = []
+    for use_async in (False, True):
+        ctx = capi.Context(0)
+        ctx.resize(W, H)
+        ctx.upload_scene(sc)
+        ctx.set_camera(cam)
+        ctx.set_tuning(11, pipelined)
+        for f, tech in enumerate(seq):
+            st = settings_for(tech)
+            st.rand_seed = f + 1
+            if f == 10:
+                ctx.reset_frame_index()                    # the accumulator restarts while earlier frames may still be in flight
+            if use_async and f != 7:
+                ctx.render_async(st)
+            else:
+                ctx.render(st)
+        ctx.synchronize()
+        img, acc = ctx.readback()
+        bufs = [ctx.read_buffer(b) for b in (capi.BUF_DI, capi.BUF_DI_PREV, capi.BUF_DEPTH)]
+        outs.append((img, acc, bufs))
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert a.tobytes() == b.tobytes()
