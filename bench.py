@@ -14,6 +14,11 @@ The CPU oracle is used ONLY in the `cpu_baseline` leg (rank 0, N = 1).
 from __future__ import annotations
 
 import argparse
+import os
+
+# More hardware queues than HIP's default 4, set before anything initialises HIP (torch included): the library pipelines
+# frames over two streams, torch and RCCL bring their own, and streams that share a hardware queue do not overlap.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import json
 import os
 import sys
@@ -60,6 +65,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rehearse-gather", action="store_true", help="N = 1 only: run the per-frame RCCL all-gather path with a one-rank group (checks RCCL beside the pipelined streams)")
     ap.add_argument("--set", nargs="*", default=[], metavar="KEY=VALUE", help="fyprt_set_tuning knobs (experiments)")
     args = ap.parse_args()
 
@@ -79,7 +85,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if N > 1:
+    G = N > 1 or args.rehearse_gather               # frames are followed by an all-gather of the image bands
+    if G:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -135,7 +144,7 @@ def main():
             pending[k] = None
         ctx.set_external_image(images[k].data_ptr())
         ctx.render_async(st)
-        if N > 1:
+        if G:
             image = images[k]
             band = image[r0 * W: r0 * W + rows_per * W] if r1 - r0 == rows_per else torch.nn.functional.pad(image[r0 * W: r1 * W], (0, (rows_per - (r1 - r0)) * W))
             with torch.cuda.stream(ext_stream):       # RCCL waits for the frame's kernels, the next frame does not wait for RCCL
@@ -148,7 +157,7 @@ def main():
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
-        if N > 1:
+        if G:
             dist.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()

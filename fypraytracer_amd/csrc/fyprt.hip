@@ -117,7 +117,15 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     auto* c = new fyprt_context(); c->device = device_ordinal;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
-    e = hipStreamCreateWithFlags(&c->front, hipStreamNonBlocking);
+    {   // The front stream is created at the LOWEST priority: HIP deals the streams of one priority level round-robin over a
+        // few hardware queues (GPU_MAX_HW_QUEUES, default 4), and two streams that land on the same queue run strictly one
+        // after the other.  With torch + RCCL streams in the process both of ours shared a queue and nothing overlapped
+        // (1.12 instead of 0.99 ms per frame); a different priority level uses a different set of queues (1.00 ms), and with
+        // GPU_MAX_HW_QUEUES=8 in the environment as well, 0.98 ms with or without the per-frame gather (profiles/README.md).
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&c->front, hipStreamNonBlocking, lo);
+    }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) { e = hipEventCreateWithFlags(&c->evFront[k], hipEventDisableTiming); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming); }
     if (e != hipSuccess) { g_createError = std::string("front stream / events: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
     for (auto& row : c->ring) for (auto& e : row) (void)hipEventCreate(&e);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--scene", default="hall")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--async-frames", type=int, default=0, help="measure wall ms/frame over this many asynchronous (pipelined) frames instead of blocking frames")
     ap.add_argument("--lib", default=None, help="alternative libfyprt build to load")
     ap.add_argument("--set", nargs="*", default=[], help="fixed knobs key=value")
     a = ap.parse_args()
@@ -42,10 +43,24 @@ def main():
     st = capi.Settings(technique=a.technique, light_bounces=2 if a.technique != 7 else 1, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
     res = {v: [] for v in a.values}
     allparts = {}
+    import time
+    wall = {v: [] for v in a.values}
     for r in range(a.rounds):
         for v in a.values:
             ctx.set_tuning(a.key, v)
             ctx.reset_frame_index()
+            if a.async_frames:
+                for f in range(10):
+                    st.rand_seed = f + 1
+                    ctx.render_async(st)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                for f in range(a.async_frames):
+                    st.rand_seed = 11 + f
+                    ctx.render_async(st)
+                ctx.synchronize()
+                wall[v].append((time.perf_counter() - t0) / a.async_frames * 1e3)
+                continue
             parts = []
             for f in range(a.frames):
                 st.rand_seed = f + 1
@@ -54,6 +69,10 @@ def main():
                     parts.append([s.kernel_ms_part[0], sum(list(s.kernel_ms_part)[1:])])
             res[v].append(np.median(np.array(parts), axis=0))
             allparts.setdefault(v, []).append(list(s.kernel_ms_part))
+    if a.async_frames:
+        for v in a.values:
+            print(json.dumps({"key": a.key, "value": v, "async_wall_ms_per_frame_median": round(float(np.median(wall[v])), 4), "min": round(float(np.min(wall[v])), 4)}))
+        return
     for v in a.values:
         m = np.array(res[v])
         print(json.dumps({"key": a.key, "value": v, "p1_ms_median": round(float(np.median(m[:, 0])), 4), "p2_ms_median": round(float(np.median(m[:, 1])), 4),
