@@ -2,13 +2,19 @@
 // persistent-thread work stealing"):
 //
 //   k_di_part2_setup  one thread per pixel: spatial reuse, light-point sample, BRDF — everything of
-//                     PerPixel_ReSTIR_DI_Part2 (R.cu:1875-2007, :2033-2038) except the shadow ray; live pixels
-//                     append one 64-byte shadow task to a queue (wave ballot + prefix popcount, one atomic per wave).
-//   k_di_part2_trace  persistent waves: every lane owns one in-flight shadow ray; when >= kRefillLanes lanes of a wave
-//                     have finished, the wave steals the next tasks from the queue head (one atomic per refill) and
-//                     refills exactly those lanes, so SIMD lanes stay busy although shadow rays differ 10x in length
-//                     (measured lane utilisation of the one-thread-per-pixel Part 2: 35 %).  A finished lane runs the
-//                     fused epilogue for its pixel (visibility select, accumulate, tonemap, pack) and goes idle.
+//                     PerPixel_ReSTIR_DI_Part2 (R.cu:1875-2007, :2033-2038) except the shadow ray; every pixel of the band
+//                     appends one 64-byte task to a queue (wave ballot + prefix popcount, LDS prefix over the 4 waves, ONE
+//                     atomic per workgroup): a shadow task, or — for a pixel Part 1 finished (sky / emitter) — a task
+//                     without a ray that only carries the pixel's colour to the epilogue.
+//   k_di_part2_trace  persistent waves: every lane owns one in-flight shadow ray; when >= refillLanes lanes of a wave are
+//                     idle, the wave runs their fused epilogues together (visibility select, accumulate, tonemap, pack)
+//                     and refills exactly those lanes from its claimed chunk of the queue, so SIMD lanes stay busy although
+//                     shadow rays differ 10x in length (lane utilisation of the one-thread-per-pixel Part 2: 35 %).
+//                     Chunks: the first one of every wave is static, the rest are stolen from a shared head and shrink
+//                     towards the end of the queue (see the kernel).
+//
+// All epilogues of a wavefront frame run in the trace kernel, and Part 1 touches neither image nor accumulation
+// (DevFrame::p1Mode): that is what lets the host run Part 1 + setup of the next frame on a second stream beside it.
 //
 // Same arithmetic, same per-ray traversal (trace_shadow of rt_device.h, incl. the closest-hit fallback), so every
 // output bit and every instrumentation count is unchanged — only the mapping of rays to lanes differs.
