@@ -122,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_create", "fyprt_destroy", "fyprt_last_error", "fyprt_resize", "fyprt_set_rows", "fyprt_upload_scene",
     "fyprt_set_camera", "fyprt_render", "fyprt_render_async", "fyprt_synchronize", "fyprt_readback",
     "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer", "fyprt_frame_timings",
-    "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees", "fyprt_get_tuning",
+    "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees", "fyprt_get_tuning", "fyprt_update_vertices",
     "fyprt_set_ray_counting", "fyprt_set_tuning", "fyprt_version",
 ]
 
@@ -166,6 +166,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_reset_frame_index.argtypes = [vp]
     lib.fyprt_frame_index.argtypes = [vp]
     lib.fyprt_frame_index.restype = u32
+    lib.fyprt_update_vertices.argtypes = [vp, vp, u32]
     lib.fyprt_get_tuning.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     lib.fyprt_export_bvh.argtypes = [vp, vp, C.POINTER(u32), vp, C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]
     lib.fyprt_export_lighttrees.argtypes = [vp, vp, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(u32), vp, vp, vp]
@@ -332,6 +333,11 @@ class Context:
 
     def set_tuning(self, key: int, value: int):
         self._check(self.lib.fyprt_set_tuning(self.h, key, value))
+
+    def update_vertices(self, scene):
+        """Moved geometry, same topology: refit on the device (fyprt_update_vertices)."""
+        v = np.ascontiguousarray(scene.world_vertices)
+        self._check(self.lib.fyprt_update_vertices(self.h, v.ctypes.data, len(v)))
 
     def get_tuning(self, key: int) -> int:
         v = C.c_int()

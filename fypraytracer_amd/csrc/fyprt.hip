@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "rt_host.h"
+#include "rt_refit.h"
 #include "rt_wavefront.h"
 
 using namespace rt;
@@ -56,6 +57,11 @@ struct fyprt_context {
     DevBuf<DIRec> drec, dprevA, dprevB; bool dprevFlip = false; int lastTech = -1;
     uint32_t* externalImage = nullptr;
     // scene
+    // what a device refit needs beyond the tree itself (fyprt_update_vertices): vertices, per-triangle vertex indices, the nodes of
+    // every level (bottom level first), a box per node; and the topology the host light-tree builder is fed again
+    DevBuf<DevVertex> dverts; DevBuf<uint4> triIdx; DevBuf<uint32_t> levelNodes; DevBuf<float4> nodeBox; std::vector<uint32_t> levelOffset;
+    std::vector<uint32_t> topoTris; std::vector<fyprt_mesh> topoMeshes; std::vector<fyprt_material> topoMats; uint32_t vertexCount = 0; bool prebuiltLightTrees = false;
+    bool hostBvhStale = false;                      // the device tree was refitted: fyprt_export_bvh reads it back first
     DevBuf<float4> nodes, leafTris, triPos, triShade, mats; DevBuf<DevTexture> texTable; std::vector<DevBuf<uint32_t>> texPixels;
     DevBuf<uint32_t> emissive; DevBuf<float4> lightRecs; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot, ltLeafOfTri;
     DevBuf<unsigned long long> rayCounter;
@@ -251,6 +257,24 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     }
     HIPCHK(c, c->triPos.alloc((size_t)nT * 3)); HIPCHK(c, c->triShade.alloc((size_t)nT * 4));
     if (upload(c, c->triPos.p, pos.data(), c->triPos.bytes()) || upload(c, c->triShade.p, shade.data(), c->triShade.bytes())) return FYPRT_EHIP;
+    // refit support: vertices + per-triangle indices on the device, nodes grouped by level (levels = 1 first)
+    c->vertexCount = s->vertex_count; c->hostBvhStale = false;
+    c->topoTris.resize((size_t)nT * 4);
+    for (uint32_t i = 0; i < nT; ++i) std::memcpy(&c->topoTris[(size_t)i * 4], tri(i), 16);
+    c->topoMeshes.assign(s->meshes, s->meshes + s->mesh_count); c->topoMats.assign(s->materials, s->materials + s->material_count);
+    c->prebuiltLightTrees = s->light_trees && s->light_trees->tlas_nodes;
+    {
+        const std::vector<rth::Node>& hn = c->hostBvh.nodes;
+        const uint32_t L = c->hostBvh.levels;
+        c->levelOffset.assign(L + 2, 0);
+        for (const rth::Node& n : hn) c->levelOffset[(n.meta >> 3) + 1]++;
+        for (uint32_t l = 1; l <= L + 1; ++l) c->levelOffset[l] += c->levelOffset[l - 1];      // levelOffset[l] = first slot of level l (1-based levels)
+        std::vector<uint32_t> order(hn.size()), fill(c->levelOffset.begin(), c->levelOffset.end());
+        for (uint32_t i = 0; i < (uint32_t)hn.size(); ++i) order[fill[hn[i].meta >> 3]++] = i;
+        HIPCHK(c, c->dverts.alloc(s->vertex_count)); HIPCHK(c, c->triIdx.alloc(nT)); HIPCHK(c, c->levelNodes.alloc(order.size())); HIPCHK(c, c->nodeBox.alloc(hn.size() * 2));
+        if (upload(c, c->dverts.p, s->vertices, c->dverts.bytes()) || upload(c, c->triIdx.p, c->topoTris.data(), c->triIdx.bytes()) ||
+            upload(c, c->levelNodes.p, order.data(), c->levelNodes.bytes())) return FYPRT_EHIP;
+    }
     // materials (Material.cuh:7-16 -> 3 quads)
     std::vector<float> mats((size_t)s->material_count * 12, 0.0f);
     std::vector<char> emissiveMat(s->material_count, 0);
@@ -337,6 +361,63 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
         HIPCHK(c, sync_all(c));
     }
     c->haveScene = true;
+    return FYPRT_OK;
+}
+
+
+// (Re)build the light trees from the given vertices with the stored topology and upload them (+ the emitter -> TLAS-leaf table).
+static int rebuild_light_trees(fyprt_context* c, const fyprt_vertex* verts) {
+    rth::LightTrees& lt = c->hostLt; lt = rth::LightTrees();
+    const uint32_t nT = (uint32_t)(c->topoTris.size() / 4), nM = (uint32_t)c->topoMeshes.size();
+    rth::BuildLightTrees(verts, (const uint8_t*)c->topoTris.data(), 16, c->topoMeshes.data(), nM, c->topoMats.data(), lt);
+    HIPCHK(c, c->ltTlas.alloc(lt.tlas.size())); HIPCHK(c, c->ltBlas.alloc(lt.blas.size()));
+    HIPCHK(c, c->ltFirst.alloc(nM)); HIPCHK(c, c->ltCount.alloc(nM)); HIPCHK(c, c->ltRoot.alloc(nM));
+    if (upload(c, c->ltTlas.p, lt.tlas.data(), c->ltTlas.bytes()) || upload(c, c->ltBlas.p, lt.blas.data(), c->ltBlas.bytes()) ||
+        upload(c, c->ltFirst.p, lt.first.data(), c->ltFirst.bytes()) || upload(c, c->ltCount.p, lt.count.data(), c->ltCount.bytes()) ||
+        upload(c, c->ltRoot.p, lt.root.data(), c->ltRoot.bytes())) return FYPRT_EHIP;
+    std::vector<uint32_t> leafOfTri(nT, ~0u);
+    for (uint32_t i = 0; i < (uint32_t)lt.tlas.size(); ++i) {
+        if (!lt.tlas[i].is_leaf) continue;
+        const uint32_t mesh = lt.tlas[i].right_or_emitter;
+        if (mesh >= nM) continue;
+        for (uint32_t j = 0; j < lt.count[mesh]; ++j) {
+            const fyprt_lighttree_node& n = lt.blas[lt.first[mesh] + j];
+            if (n.is_leaf && n.right_or_emitter < nT && leafOfTri[n.right_or_emitter] == ~0u) leafOfTri[n.right_or_emitter] = i;
+        }
+    }
+    HIPCHK(c, c->ltLeafOfTri.alloc(nT));
+    if (upload(c, c->ltLeafOfTri.p, leafOfTri.data(), c->ltLeafOfTri.bytes())) return FYPRT_EHIP;
+    DevScene& d = c->dsc;
+    d.ltLeafOfTri = c->ltLeafOfTri.p; d.ltTlas = c->ltTlas.p; d.ltTlasCount = (uint32_t)lt.tlas.size(); d.ltTlasRoot = lt.tlasRoot;
+    d.ltBlas = c->ltBlas.p; d.ltFirst = c->ltFirst.p; d.ltCount = c->ltCount.p; d.ltRoot = c->ltRoot.p;
+    return FYPRT_OK;
+}
+
+// Scene geometry moved, topology unchanged (SceneManager::PerformAllSceneUpdates with a transform edit, SceneManager.cpp:24-66):
+// new world vertices -> per-triangle records, leaf triangles and the tree's boxes are refreshed ON THE DEVICE (rt_refit.h),
+// the per-light records are rebuilt by their kernel, the (small) light trees on the host.  The tree keeps its shape.
+int fyprt_update_vertices(fyprt_context* c, const fyprt_vertex* vertices, uint32_t vertex_count) {
+    if (!c || !vertices) return FYPRT_EINVAL;
+    if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_update_vertices before fyprt_upload_scene");
+    if (vertex_count != c->vertexCount) return c->fail(FYPRT_EINVAL, "fyprt_update_vertices: vertex count differs from the uploaded scene");
+    if (c->hostOnly) return c->fail(FYPRT_ESTATE, "fyprt_update_vertices needs a device (host-only context)");
+    if (c->prebuiltLightTrees) return c->fail(FYPRT_ESTATE, "fyprt_update_vertices: the scene was uploaded with prebuilt light trees; upload it again instead");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
+    const uint32_t nT = (uint32_t)(c->topoTris.size() / 4), nLeaf = (uint32_t)c->hostBvh.tris.size(), nNodes = (uint32_t)c->hostBvh.nodes.size();
+    if (upload(c, c->dverts.p, vertices, c->dverts.bytes())) return FYPRT_EHIP;
+    if (nT) hipLaunchKernelGGL(k_refresh_triangles, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->dverts.p, c->triIdx.p, c->triPos.p, c->triShade.p, nT);
+    if (nLeaf) hipLaunchKernelGGL(k_refresh_leaf_tris, dim3((nLeaf + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, c->leafTris.p, nLeaf);
+    for (uint32_t l = 1; nNodes && l <= c->hostBvh.levels; ++l) {                 // bottom level first: a node needs its children's boxes
+        const uint32_t first = c->levelOffset[l], count = c->levelOffset[l + 1] - first;
+        if (count) hipLaunchKernelGGL(k_refit_level, dim3((count + 127u) / 128u), dim3(128), 0, c->stream, c->nodes.p, c->levelNodes.p + first, count, c->leafTris.p, c->triPos.p, c->nodeBox.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->hostBvhStale = true;
+    int rc = rebuild_light_trees(c, vertices);
+    if (rc != FYPRT_OK) return rc;
+    if (c->dsc.emissiveCount) hipLaunchKernelGGL(k_build_light_records, dim3((c->dsc.emissiveCount + 255u) / 256u), dim3(256), 0, c->stream, c->dsc, c->lightRecs.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, sync_all(c));
     return FYPRT_OK;
 }
 
@@ -594,6 +675,12 @@ uint32_t fyprt_frame_index(const fyprt_context* c) { return c ? c->frameIndex : 
 int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void* tris48, uint32_t* tri_count, int32_t* root_ref, uint32_t* max_stack) {
     if (!c) return FYPRT_EINVAL;
     if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_export_bvh before fyprt_upload_scene");
+    if (c->hostBvhStale && !c->hostOnly) {              // the device refitted the tree: read it back
+        HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
+        if (!c->hostBvh.nodes.empty()) HIPCHK(c, hipMemcpy(c->hostBvh.nodes.data(), c->nodes.p, c->hostBvh.nodes.size() * 64, hipMemcpyDeviceToHost));
+        if (!c->hostBvh.tris.empty()) HIPCHK(c, hipMemcpy(c->hostBvh.tris.data(), c->leafTris.p, c->hostBvh.tris.size() * 48, hipMemcpyDeviceToHost));
+        c->hostBvhStale = false;
+    }
     const rth::SceneBVH& b = c->hostBvh;
     if (nodes64) std::memcpy(nodes64, b.nodes.data(), b.nodes.size() * 64);
     if (tris48) std::memcpy(tris48, b.tris.data(), b.tris.size() * 48);

@@ -1,0 +1,111 @@
+// Device-side refit of the acceleration structure for moved vertices (dynamic scenes; the reference rebuilds
+// every BLAS/TLAS on the host, SceneManager.cpp:83-129).  Topology (triangles, meshes, materials, tree shape) is kept; what
+// changes with the vertices is recomputed where it lives:
+//   k_refresh_triangles   per triangle: position record (triPos) and shading record (triShade) from the new vertices
+//   k_refresh_leaf_tris   per leaf triangle: (v0, e1, e2) from the new positions
+//   k_refit_level         per node of one level (levels = 1 first: all children are leaves): exact child boxes from the leaf
+//                         triangles / the children's own boxes, then the node's grid (origin, power-of-two steps) and the 8-bit
+//                         child planes with the host builder's rule (lo planes down, hi planes up, 1/16 step of slack,
+//                         verified in fp32) — bvh_build.cpp: Collapser::quantise
+// The tree keeps its shape, so its SAH quality degrades with large deformations; a full fyprt_upload_scene rebuilds it.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+struct DevVertex { float px, py, pz, nx, ny, nz, u, v; };
+
+__global__ void k_refresh_triangles(const DevVertex* verts, const uint4* triIdx, float4* triPos, float4* triShade, uint32_t nT) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nT) return;
+    const uint4 ix = triIdx[t];
+    const DevVertex a = verts[ix.x], b = verts[ix.y], c = verts[ix.z];
+    const float mat = __int_as_float((int)ix.w);
+    float4* p = triPos + (size_t)t * 3; float4* q = triShade + (size_t)t * 4;
+    p[0] = make_float4(a.px, a.py, a.pz, mat); p[1] = make_float4(b.px, b.py, b.pz, 0.0f); p[2] = make_float4(c.px, c.py, c.pz, 0.0f);
+    q[0] = make_float4(a.nx, a.ny, a.nz, a.u); q[1] = make_float4(b.nx, b.ny, b.nz, a.v); q[2] = make_float4(c.nx, c.ny, c.nz, b.u);
+    q[3] = make_float4(b.v, c.u, c.v, mat);
+}
+
+__global__ void k_refresh_leaf_tris(const float4* triPos, float4* leafTris, uint32_t nLeaf) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nLeaf) return;
+    float4* r = leafTris + (size_t)j * 3;
+    const float4 c = r[2];
+    const uint32_t tri = (uint32_t)__float_as_int(c.y);
+    const float4* p = triPos + (size_t)tri * 3;
+    const float4 a = p[0], b = p[1], d = p[2];
+    r[0] = make_float4(a.x, a.y, a.z, b.x - a.x);
+    r[1] = make_float4(b.y - a.y, b.z - a.z, d.x - a.x, d.y - a.y);
+    r[2] = make_float4(d.z - a.z, c.y, c.z, c.w);
+}
+
+struct RBox { float lo[3], hi[3]; };
+RT_DEV void rbox_grow(RBox& b, float x, float y, float z) {
+    b.lo[0] = __builtin_fminf(b.lo[0], x); b.lo[1] = __builtin_fminf(b.lo[1], y); b.lo[2] = __builtin_fminf(b.lo[2], z);
+    b.hi[0] = __builtin_fmaxf(b.hi[0], x); b.hi[1] = __builtin_fmaxf(b.hi[1], y); b.hi[2] = __builtin_fmaxf(b.hi[2], z);
+}
+
+// nodeBox: 2 float4 per node (lo.xyz, hi.xyz), written for every node processed
+__global__ void k_refit_level(float4* nodes, const uint32_t* levelNodes, uint32_t count, const float4* leafTris, const float4* triPos, float4* nodeBox) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t node = levelNodes[k];
+    float4* n = nodes + (size_t)node * 4;
+    const float4 q0 = n[0], q1 = n[1];
+    const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u;
+    const int32_t child[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
+    RBox cb[4]; RBox nb;
+    const float big = 3.402823466e+38f;
+    for (int a = 0; a < 3; ++a) { nb.lo[a] = big; nb.hi[a] = -big; }
+    for (uint32_t i = 0; i < cnt; ++i) {
+        RBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = big; b.hi[a] = -big; }
+        if (child[i] >= 0) {
+            const float4 l = nodeBox[(size_t)child[i] * 2], h = nodeBox[(size_t)child[i] * 2 + 1];
+            b.lo[0] = l.x; b.lo[1] = l.y; b.lo[2] = l.z; b.hi[0] = h.x; b.hi[1] = h.y; b.hi[2] = h.z;
+        } else {
+            const uint32_t code = (uint32_t)~child[i], first = code >> 2, m = (code & 3u) + 1u;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t tri = (uint32_t)__float_as_int(leafTris[(size_t)(first + j) * 3 + 2].y);
+                const float4* p = triPos + (size_t)tri * 3;
+                const float4 a = p[0], bb = p[1], c = p[2];
+                rbox_grow(b, a.x, a.y, a.z); rbox_grow(b, bb.x, bb.y, bb.z); rbox_grow(b, c.x, c.y, c.z);
+            }
+        }
+        cb[i] = b;
+        for (int a = 0; a < 3; ++a) { nb.lo[a] = __builtin_fminf(nb.lo[a], b.lo[a]); nb.hi[a] = __builtin_fmaxf(nb.hi[a], b.hi[a]); }
+    }
+    uint32_t exps = ex & 0xFF000000u, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+        const float lo = nb.lo[a];
+        const double ext = (double)nb.hi[a] - (double)lo;
+        int e = 1;
+        if (ext > 0.0) { int ee; const double m = frexp(ext / 254.0, &ee); if (m == 0.5) --ee; e = ee + 127; e = e < 1 ? 1 : (e > 254 ? 254 : e); }
+        uint32_t wl = 0, wh = 0;
+        for (;; ++e) {
+            const double s = ldexp(1.0, e - 127); const float sf = (float)s;
+            bool ok = ext <= 254.0 * s;
+            wl = 0; wh = 0;
+            for (uint32_t i = 0; i < 4; ++i) {
+                int ql = 255, qh = 0;                                  // unused slots: the inverted box no ray can hit
+                if (i < cnt && ok) {
+                    ql = (int)floor(((double)cb[i].lo[a] - (double)lo) / s - 0.0625); qh = (int)ceil(((double)cb[i].hi[a] - (double)lo) / s + 0.0625);
+                    ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                    while (ql > 0 && !(__builtin_fmaf((float)ql, sf, lo) <= cb[i].lo[a])) --ql;
+                    while (qh < 255 && !(__builtin_fmaf((float)qh, sf, lo) >= cb[i].hi[a])) ++qh;
+                    ok = __builtin_fmaf((float)ql, sf, lo) <= cb[i].lo[a] && __builtin_fmaf((float)qh, sf, lo) >= cb[i].hi[a];
+                }
+                wl |= (uint32_t)ql << (8 * i); wh |= (uint32_t)qh << (8 * i);
+            }
+            if (ok || e >= 254) break;
+        }
+        exps |= (uint32_t)e << (8 * a); qlo[a] = wl; qhi[a] = wh;
+    }
+    n[0] = make_float4(nb.lo[0], nb.lo[1], nb.lo[2], __int_as_float((int)exps));
+    n[2] = make_float4(__int_as_float((int)qlo[0]), __int_as_float((int)qlo[1]), __int_as_float((int)qlo[2]), __int_as_float((int)qhi[0]));
+    n[3] = make_float4(__int_as_float((int)qhi[1]), __int_as_float((int)qhi[2]), 0.0f, 0.0f);
+    nodeBox[(size_t)node * 2] = make_float4(nb.lo[0], nb.lo[1], nb.lo[2], 0.0f);
+    nodeBox[(size_t)node * 2 + 1] = make_float4(nb.hi[0], nb.hi[1], nb.hi[2], 0.0f);
+}
+
+}  // namespace rt

@@ -212,6 +212,13 @@ int fyprt_stream(fyprt_context* ctx, void** stream);
 
 int fyprt_read_buffer(fyprt_context* ctx, int which /* enum fyprt_buffer */, void* dst, size_t bytes);
 
+/* The geometry moved, the topology did not (a transform edit through SceneManager::PerformAllSceneUpdates,
+ * SceneManager.cpp:24-66, where the reference rebuilds the mesh's BLAS, the TLAS and the light trees on the host): the new world
+ * vertices (same count and order as uploaded) refresh the per-triangle records, the leaf triangles and the boxes of the
+ * acceleration structure ON THE DEVICE; the tree keeps its shape (fyprt_upload_scene rebuilds it).  Light records are rebuilt by
+ * their kernel, the light trees on the host.  Not available for scenes uploaded with prebuilt light trees. */
+int fyprt_update_vertices(fyprt_context* ctx, const fyprt_vertex* vertices, uint32_t vertex_count);
+
 /* Renderer::ResetFrameIndex / GetCurrentFrameIndex (Renderer.h:47,49). */
 int fyprt_reset_frame_index(fyprt_context* ctx);
 uint32_t fyprt_frame_index(const fyprt_context* ctx);

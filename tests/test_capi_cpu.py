@@ -8,7 +8,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from common import struct_equal
+from common import check_bvh_invariants, struct_equal
 from fypraytracer_amd import capi, scenes
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -73,51 +73,7 @@ def test_bvh_invariants(name):
     ctx = capi.Context(-1)
     ctx.upload_scene(sc)
     b = ctx.export_bvh()
-    nodes, tris = b["nodes"], b["tris"]
-    assert sorted(tris["tri"].tolist()) == list(range(len(sc.triangles)))   # every triangle exactly once
-    assert b["max_stack"] <= 31                                              # wide levels: what node_step's stack rule needs (<= 31)
-    pos = sc.world_vertices["position"]
-    t = sc.triangles
-    # leaf records are (v0, v1 - v0, v2 - v0) of the original triangle, bit for bit
-    i = tris["tri"]
-    assert np.array_equal(tris["v0"], pos[t["v0"][i]])
-    assert np.array_equal(tris["e1"], pos[t["v1"][i]] - pos[t["v0"][i]])
-    assert np.array_equal(tris["e2"], pos[t["v2"][i]] - pos[t["v0"][i]])
-    # every child box bounds everything below it; every node reachable exactly once from the root
-    tri_lo = np.minimum(np.minimum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
-    tri_hi = np.maximum(np.maximum(pos[t["v0"]], pos[t["v1"]]), pos[t["v2"]])
-    seen = np.zeros(len(nodes), dtype=int)
-    assert (((nodes["meta"] & 7) >= 2) & ((nodes["meta"] & 7) <= 4)).all() and len(nodes) < (1 << 26)
-
-    def bounds(ref):
-        """-> (lo, hi, wide levels) of the subtree; checks that every quantised child box contains everything below it."""
-        if ref >= 0:
-            seen[ref] += 1
-            n = nodes[ref]
-            k = int(n["meta"]) & 7
-            step = np.ldexp(np.float32(1.0), n["ex"].astype(np.int32) - 127).astype(np.float32)
-            lo_all, hi_all, need = [], [], 0
-            for i in range(k):
-                l, h, cn = bounds(int(n["child"][i]))
-                qlo = (n["origin"] + n["qlo"][:, i].astype(np.float32) * step).astype(np.float32)   # exact: q * 2^e, then one rounding
-                qhi = (n["origin"] + n["qhi"][:, i].astype(np.float32) * step).astype(np.float32)
-                assert (qlo <= l).all() and (qhi >= h).all()
-                lo_all.append(l); hi_all.append(h); need = max(need, cn)
-            assert (n["qlo"][:, k:] == 255).all() and (n["qhi"][:, k:] == 0).all()                       # unused slots: inverted box
-            assert (n["origin"] == np.min(lo_all, axis=0)).all()                                      # grid anchored at the node's own box
-            assert int(n["meta"]) >> 3 == 1 + need                                                    # recorded level count
-            return np.min(lo_all, axis=0), np.max(hi_all, axis=0), 1 + need
-        code = ~ref
-        first, cnt = code >> 2, (code & 3) + 1
-        ids = tris["tri"][first:first + cnt]
-        return tri_lo[ids].min(0), tri_hi[ids].max(0), 0
-
-    import sys
-    sys.setrecursionlimit(10000)
-    _, _, need = bounds(b["root"])
-    assert (seen == 1).all()
-    assert need == b["max_stack"] <= 31
-    assert (nodes["meta"] & 7).mean() > 3.0                                  # the collapse really is wide
+    check_bvh_invariants(b, sc)
     ctx.close()
 
 
