@@ -47,7 +47,17 @@ public:
     }
 
     template <class SceneT, class CameraT> void Render(SceneT& scene, CameraT& camera) {   // Renderer.cu:13-284
-        if (isSceneUpdated) { UploadScene(scene); isSceneUpdated = false; }                   // :61-69
+        if (isSceneUpdated) {                                                                 // :61-69
+            // only vertices moved since the last upload (a transform edit): refit on the device instead of a full rebuild
+            const uint64_t sig = TopologySignature(scene);
+            if (m_HaveScene && sig == m_TopologySig &&
+                fyprt_update_vertices(m_Ctx, reinterpret_cast<const fyprt_vertex*>(scene.worldVertices.data()), (uint32_t)scene.worldVertices.size()) == FYPRT_OK) {
+                ++m_Refits;
+            } else {
+                UploadScene(scene); m_TopologySig = sig; m_HaveScene = true; ++m_Uploads;
+            }
+            isSceneUpdated = false;
+        }
         fyprt_camera_desc c{};                                                                // :70 CameraToGPU
         std::memcpy(c.projection, &camera.GetProjection(), 64); std::memcpy(c.view, &camera.GetView(), 64);
         std::memcpy(c.prev_projection, &camera.GetPrevProjection(), 64); std::memcpy(c.prev_view, &camera.GetPrevView(), 64);
@@ -76,8 +86,24 @@ public:
     void SetPresenter(std::function<void(const uint32_t*, uint32_t, uint32_t)> p) { m_Present = std::move(p); }
     const fyprt_frame_stats& GetLastFrameStats() const { return m_LastStats; }
     fyprt_context* GetContext() const { return m_Ctx; }
+    uint32_t GetSceneUploadCount() const { return m_Uploads; }
+    uint32_t GetSceneRefitCount() const { return m_Refits; }
 
 private:
+    // FNV-1a over everything of the scene except vertex positions / normals: triangles (indices + material), meshes, materials,
+    // emissive list, texture identities, vertex count
+    template <class SceneT> static uint64_t TopologySignature(const SceneT& scene) {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+        const uint64_t counts[5] = {scene.worldVertices.size(), scene.triangles.size(), scene.meshes.size(), scene.materials.size(), scene.textures.size()};
+        mix(counts, sizeof counts);
+        for (const auto& t : scene.triangles) { const uint32_t v[4] = {t.v0, t.v1, t.v2, (uint32_t)t.materialIndex}; mix(v, sizeof v); }
+        for (const auto& m : scene.meshes) { const uint32_t v[3] = {m.indexStart, m.indexCount, (uint32_t)m.materialIndex}; mix(v, sizeof v); }
+        if (!scene.materials.empty()) mix(scene.materials.data(), scene.materials.size() * sizeof(scene.materials[0]));
+        if (!scene.emissiveTriangles.empty()) mix(scene.emissiveTriangles.data(), scene.emissiveTriangles.size() * 4);
+        for (const auto& t : scene.textures) { const uint64_t v[3] = {(uint64_t)(uintptr_t)t.pixels, t.width, t.height}; mix(v, sizeof v); }
+        return h;
+    }
     template <class SceneT> void UploadScene(SceneT& scene) {                                 // SceneToGPU, Scene_GPU.cpp:6-81
         fyprt_scene_desc d{};
         d.vertices = reinterpret_cast<const fyprt_vertex*>(scene.worldVertices.data()); d.vertex_count = (uint32_t)scene.worldVertices.size();
@@ -108,6 +134,7 @@ private:
     std::vector<uint32_t> m_RenderImageData;
     std::vector<float> m_AccumulationData;
     bool isSceneUpdated = true;
+    bool m_HaveScene = false; uint64_t m_TopologySig = 0; uint32_t m_Uploads = 0, m_Refits = 0;
     std::function<void(const uint32_t*, uint32_t, uint32_t)> m_Present;
     fyprt_frame_stats m_LastStats{};
 };

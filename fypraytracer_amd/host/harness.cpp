@@ -46,6 +46,15 @@ int main(int argc, char** argv) {
         total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         camera.SetPrevProjection(camera.GetProjection()); camera.SetPrevView(camera.GetView()); // WalnutApp.cpp:908-909
     }
+    {   // one transform edit through the SceneManager (WalnutApp.cpp:620-662, :776): the facade refits on the device
+        Mesh& lightMesh = scene.meshes.back();
+        lightMesh.position = vec3{0.05f, 0.0f, 0.0f};
+        scene.sceneManager.meshesToUpdate.emplace_back(true, false, (uint32_t)scene.meshes.size() - 1u);
+        scene.sceneManager.PerformAllSceneUpdates(scene, renderer);
+        s.randSeed++;
+        renderer.Render(scene, camera);
+    }
+    std::printf("Scene uploads : %u, device refits : %u\n", renderer.GetSceneUploadCount(), renderer.GetSceneRefitCount());
     std::printf("Resolution : %ux%u\nTriangles : %zu\nAvg frame time : %.3fms (kernels %.3fms)\nAccumulated frames : %u\n",
                 W, H, scene.triangles.size(), total / frames, renderer.GetLastFrameStats().kernel_ms, renderer.GetCurrentFrameIndex() - 1);
     if (argc > 5 && !MisUtils::SaveABGRToBMP(argv[5], renderer.GetRenderImageDataPtr(), (int)W, (int)H)) { std::fprintf(stderr, "cannot write %s\n", argv[5]); return 1; }
