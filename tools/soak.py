@@ -13,9 +13,11 @@ sys.path.insert(0, str(ROOT))
 from fypraytracer_amd import capi, scenes  # noqa: E402
 
 
-def run(sc, cam, W, H, frames, pipelined):
+def run(sc, cam, W, H, frames, pipelined, rows=None, halo=0):
     ctx = capi.Context(0)
     ctx.resize(W, H)
+    if rows:
+        ctx.set_rows(rows[0], rows[1], halo)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
     ctx.set_tuning(11, 1 if pipelined else 0)
@@ -28,9 +30,10 @@ def run(sc, cam, W, H, frames, pipelined):
             ctx.render(st)
     ctx.synchronize()
     img, acc = ctx.readback()
-    crc = zlib.crc32(acc.tobytes(), zlib.crc32(img.tobytes()))
+    y0, y1 = rows if rows else (0, H)                      # only the rows this context owns are defined
+    crc = zlib.crc32(acc[y0:y1].tobytes(), zlib.crc32(img[y0:y1].tobytes()))
     for b in (capi.BUF_DI, capi.BUF_DI_PREV, capi.BUF_DEPTH, capi.BUF_PAYLOAD):
-        crc = zlib.crc32(ctx.read_buffer(b).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(ctx.read_buffer(b).reshape(H, W, -1)[y0:y1]).tobytes(), crc)
     ctx.close()
     return crc
 
@@ -39,11 +42,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=300)
     a = ap.parse_args()
-    for name, sc, cam, W, H, n in (("hall_small 320x180", scenes.hall_scene_small(), scenes.hall_camera(320, 180), 320, 180, a.frames),
-                                   ("hall 1920x1080", scenes.hall_scene(), scenes.hall_camera(1920, 1080), 1920, 1080, max(20, a.frames // 3))):
-        ref = run(sc, cam, W, H, n, False)
+    for name, sc, cam, W, H, n, rows in (("hall_small 320x180", scenes.hall_scene_small(), scenes.hall_camera(320, 180), 320, 180, a.frames, None),
+                                   ("hall_small 320x180 top band of 4 (30-row halo, extra row H-1)", scenes.hall_scene_small(), scenes.hall_camera(320, 180), 320, 180, a.frames, (0, 45)),
+                                   ("hall_small 320x180 interior band of 4", scenes.hall_scene_small(), scenes.hall_camera(320, 180), 320, 180, a.frames, (45, 90)),
+                                   ("hall 1920x1080", scenes.hall_scene(), scenes.hall_camera(1920, 1080), 1920, 1080, max(20, a.frames // 3), None)):
+        ref = run(sc, cam, W, H, n, False, rows, 30 if rows else 0)
         for rep in range(3):
-            got = run(sc, cam, W, H, n, True)
+            got = run(sc, cam, W, H, n, True, rows, 30 if rows else 0)
             print(name, n, "frames", "blocking", hex(ref), "pipelined", hex(got), "OK" if got == ref else "MISMATCH", flush=True)
             if got != ref:
                 sys.exit(1)
