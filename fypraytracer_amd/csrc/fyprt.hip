@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 #include "rt_host.h"
+#include <hipcub/hipcub.hpp>
+#include "rt_lbvh.h"
 #include "rt_refit.h"
 #include "rt_wavefront.h"
 
@@ -70,7 +72,7 @@ struct fyprt_context {
     int lastLaunches = 0;
     size_t queueStride = 0;                     // float4s per task queue
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[12] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[13] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
@@ -210,6 +212,78 @@ static int upload(fyprt_context* c, void* dst, const void* src, size_t bytes) {
     return c->hip(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
 }
 
+
+// the refit pass over the whole tree (rt_refit.h): leaf triangles from the per-triangle positions, then boxes + quantisation
+// level by level, bottom level first
+static int run_refit(fyprt_context* c) {
+    const uint32_t nLeaf = (uint32_t)c->hostBvh.tris.size(), nNodes = (uint32_t)c->hostBvh.nodes.size();
+    if (nLeaf) hipLaunchKernelGGL(k_refresh_leaf_tris, dim3((nLeaf + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, c->leafTris.p, nLeaf);
+    for (uint32_t l = 1; nNodes && l <= c->hostBvh.levels; ++l) {
+        const uint32_t first = c->levelOffset[l], count = c->levelOffset[l + 1] - first;
+        if (count) hipLaunchKernelGGL(k_refit_level, dim3((count + 127u) / 128u), dim3(128), 0, c->stream, c->nodes.p, c->levelNodes.p + first, count, c->leafTris.p, c->triPos.p, c->nodeBox.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    return FYPRT_OK;
+}
+
+// Device builder (tuning key 12, rt_lbvh.h): Morton keys -> radix sort -> Karras radix tree -> BFS collapse into 4-wide nodes ->
+// level counts.  Leaves c->nodes (topology only), c->leafTris (triangle indices in sorted order) and the host copy of the
+// topology (for export and the level grouping); boxes come from run_refit.  kLbvhTooDeep: more than 31 wide levels.
+constexpr int kLbvhTooDeep = -1000;
+static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32_t nV, uint32_t nT) {
+    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (uint32_t i = 0; i < nV; ++i) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], verts[i].position[a]); hi[a] = std::max(hi[a], verts[i].position[a]); }
+    float3 l3 = make_float3(lo[0], lo[1], lo[2]), ie = make_float3(hi[0] > lo[0] ? 1.0f / (hi[0] - lo[0]) : 0.0f, hi[1] > lo[1] ? 1.0f / (hi[1] - lo[1]) : 0.0f, hi[2] > lo[2] ? 1.0f / (hi[2] - lo[2]) : 0.0f);
+    struct Temps {                      // scratch of the build, freed on every way out
+        DevBuf<unsigned long long> keysA, keysB; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
+        ~Temps() { keysA.release(); keysB.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
+    } t;
+    auto &keysA = t.keysA, &keysB = t.keysB; auto& radix = t.radix; auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
+    HIPCHK(c, keysA.alloc(nT)); HIPCHK(c, keysB.alloc(nT)); HIPCHK(c, radix.alloc(nT)); HIPCHK(c, qA.alloc(nT)); HIPCHK(c, qB.alloc(nT));
+    HIPCHK(c, counters.alloc(2)); HIPCHK(c, wide.alloc((size_t)nT * 4));
+    hipLaunchKernelGGL(k_lbvh_keys, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, nT, l3, ie, keysA.p);
+    size_t tempBytes = 0;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tempBytes, keysA.p, keysB.p, (int)nT, 0, 64, c->stream));
+    HIPCHK(c, temp.alloc(tempBytes));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(temp.p, tempBytes, keysA.p, keysB.p, (int)nT, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_lbvh_radix, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, (int)nT, radix.p);
+    HIPCHK(c, c->leafTris.alloc((size_t)nT * 3));
+    hipLaunchKernelGGL(k_lbvh_leaf_order, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, nT, c->leafTris.p);
+    // BFS collapse, one launch per level; the nodes of a level are contiguous: [levelFirst[l], levelFirst[l + 1])
+    const CollapseItem rootItem{0u, 0u};
+    uint32_t h_counters[2] = {1u, 0u};
+    HIPCHK(c, hipMemcpyAsync(qA.p, &rootItem, sizeof rootItem, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(counters.p, h_counters, 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> levelFirst{0u};
+    uint32_t nIn = 1, total = 1;
+    CollapseItem *in = qA.p, *out = qB.p;
+    while (nIn) {
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3((nIn + 127u) / 128u), dim3(128), 0, c->stream, radix.p, in, nIn, out, counters.p, wide.p);
+        HIPCHK(c, hipMemcpyAsync(h_counters, counters.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        levelFirst.push_back(total);
+        nIn = h_counters[1]; total = h_counters[0];
+        h_counters[1] = 0;
+        HIPCHK(c, hipMemcpyAsync(counters.p + 1, &h_counters[1], 4, hipMemcpyHostToDevice, c->stream));
+        std::swap(in, out);
+        if (levelFirst.size() > rth::kStackBudget + 1u) return kLbvhTooDeep;
+    }
+    const uint32_t nLevels = (uint32_t)levelFirst.size() - 1u;                      // BFS levels = wide levels of the tree
+    for (uint32_t l = nLevels; l-- > 0;) {
+        const uint32_t first = levelFirst[l], count = levelFirst[l + 1] - first;
+        if (count) hipLaunchKernelGGL(k_lbvh_levels, dim3((count + 127u) / 128u), dim3(128), 0, c->stream, wide.p, first, count);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (total >= (1u << 26)) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: too many nodes for the node index range");
+    HIPCHK(c, c->nodes.alloc((size_t)total * 4));
+    HIPCHK(c, hipMemcpyAsync(c->nodes.p, wide.p, (size_t)total * 64, hipMemcpyDeviceToDevice, c->stream));
+    rth::SceneBVH& b = c->hostBvh; b = rth::SceneBVH();
+    b.nodes.resize(total); b.tris.resize(nT); b.rootRef = 0; b.levels = nLevels;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(b.nodes.data(), c->nodes.p, (size_t)total * 64, hipMemcpyDeviceToHost));      // topology + meta: the level grouping needs it
+    return FYPRT_OK;
+}
+
 int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     if (!c || !s) return FYPRT_EINVAL;
     if ((s->triangle_count && (!s->triangles || !s->vertices || s->triangle_stride < 16)) || (s->mesh_count && !s->meshes) ||
@@ -232,13 +306,19 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     }
     if (covered != s->triangle_count) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: meshes must partition the triangle list");
     struct HostOnlyGuard { bool prev; explicit HostOnlyGuard(bool on) : prev(g_hostOnlyAlloc) { g_hostOnlyAlloc = on; } ~HostOnlyGuard() { g_hostOnlyAlloc = prev; } } guard(c->hostOnly);
-    // acceleration structure (ours)
-    rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
-    if (c->hostBvh.levels > rth::kStackBudget || c->hostBvh.nodes.size() >= (size_t)(1u << 26))
-        return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: acceleration structure (" + std::to_string(c->hostBvh.levels) + " levels, " +
-                       std::to_string(c->hostBvh.nodes.size()) + " nodes) exceeds the traversal stack / node index range");
-    HIPCHK(c, c->nodes.alloc(c->hostBvh.nodes.size() * 4)); HIPCHK(c, c->leafTris.alloc(c->hostBvh.tris.size() * 3));
-    if (upload(c, c->nodes.p, c->hostBvh.nodes.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
+    // acceleration structure (ours): built on the host (binned SAH + collapse, bvh_build.cpp) or, with tuning key 12, on the
+    // device (LBVH + collapse, rt_lbvh.h — further down, once the per-triangle records are on the device)
+    bool deviceBuild = !c->hostOnly && c->tuning[12] == 1 && s->triangle_count > 4;
+    auto hostBuild = [&]() -> int {
+        rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
+        if (c->hostBvh.levels > rth::kStackBudget || c->hostBvh.nodes.size() >= (size_t)(1u << 26))
+            return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: acceleration structure (" + std::to_string(c->hostBvh.levels) + " levels, " +
+                           std::to_string(c->hostBvh.nodes.size()) + " nodes) exceeds the traversal stack / node index range");
+        HIPCHK(c, c->nodes.alloc(c->hostBvh.nodes.size() * 4)); HIPCHK(c, c->leafTris.alloc(c->hostBvh.tris.size() * 3));
+        if (upload(c, c->nodes.p, c->hostBvh.nodes.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
+        return FYPRT_OK;
+    };
+    if (!deviceBuild) { const int rc = hostBuild(); if (rc != FYPRT_OK) return rc; }
     // per-triangle gather records
     const uint32_t nT = s->triangle_count;
     std::vector<float> pos((size_t)nT * 12), shade((size_t)nT * 16);
@@ -261,6 +341,11 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     c->vertexCount = s->vertex_count; c->hostBvhStale = false;
     c->topoTris.resize((size_t)nT * 4);
     for (uint32_t i = 0; i < nT; ++i) std::memcpy(&c->topoTris[(size_t)i * 4], tri(i), 16);
+    if (deviceBuild) {
+        const int rc = build_device_lbvh(c, s->vertices, s->vertex_count, nT);
+        if (rc == kLbvhTooDeep) { deviceBuild = false; const int rc2 = hostBuild(); if (rc2 != FYPRT_OK) return rc2; }   // > 31 wide levels: the host builder bounds them
+        else if (rc != FYPRT_OK) return rc;
+    }
     c->topoMeshes.assign(s->meshes, s->meshes + s->mesh_count); c->topoMats.assign(s->materials, s->materials + s->material_count);
     c->prebuiltLightTrees = s->light_trees && s->light_trees->tlas_nodes;
     {
@@ -274,6 +359,13 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
         HIPCHK(c, c->dverts.alloc(s->vertex_count)); HIPCHK(c, c->triIdx.alloc(nT)); HIPCHK(c, c->levelNodes.alloc(order.size())); HIPCHK(c, c->nodeBox.alloc(hn.size() * 2));
         if (upload(c, c->dverts.p, s->vertices, c->dverts.bytes()) || upload(c, c->triIdx.p, c->topoTris.data(), c->triIdx.bytes()) ||
             upload(c, c->levelNodes.p, order.data(), c->levelNodes.bytes())) return FYPRT_EHIP;
+    }
+    if (deviceBuild) {                     // the device builder leaves boxes and quantisation to the refit pass
+        const int rc = run_refit(c);
+        if (rc != FYPRT_OK) return rc;
+        HIPCHK(c, sync_all(c));
+        HIPCHK(c, hipMemcpy(c->hostBvh.nodes.data(), c->nodes.p, c->hostBvh.nodes.size() * 64, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->hostBvh.tris.data(), c->leafTris.p, c->hostBvh.tris.size() * 48, hipMemcpyDeviceToHost));
     }
     // materials (Material.cuh:7-16 -> 3 quads)
     std::vector<float> mats((size_t)s->material_count * 12, 0.0f);
@@ -403,15 +495,10 @@ int fyprt_update_vertices(fyprt_context* c, const fyprt_vertex* vertices, uint32
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "fyprt_update_vertices needs a device (host-only context)");
     if (c->prebuiltLightTrees) return c->fail(FYPRT_ESTATE, "fyprt_update_vertices: the scene was uploaded with prebuilt light trees; upload it again instead");
     HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
-    const uint32_t nT = (uint32_t)(c->topoTris.size() / 4), nLeaf = (uint32_t)c->hostBvh.tris.size(), nNodes = (uint32_t)c->hostBvh.nodes.size();
+    const uint32_t nT = (uint32_t)(c->topoTris.size() / 4);
     if (upload(c, c->dverts.p, vertices, c->dverts.bytes())) return FYPRT_EHIP;
     if (nT) hipLaunchKernelGGL(k_refresh_triangles, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->dverts.p, c->triIdx.p, c->triPos.p, c->triShade.p, nT);
-    if (nLeaf) hipLaunchKernelGGL(k_refresh_leaf_tris, dim3((nLeaf + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, c->leafTris.p, nLeaf);
-    for (uint32_t l = 1; nNodes && l <= c->hostBvh.levels; ++l) {                 // bottom level first: a node needs its children's boxes
-        const uint32_t first = c->levelOffset[l], count = c->levelOffset[l + 1] - first;
-        if (count) hipLaunchKernelGGL(k_refit_level, dim3((count + 127u) / 128u), dim3(128), 0, c->stream, c->nodes.p, c->levelNodes.p + first, count, c->leafTris.p, c->triPos.p, c->nodeBox.p);
-    }
-    HIPCHK(c, hipGetLastError());
+    { const int rr = run_refit(c); if (rr != FYPRT_OK) return rr; }
     c->hostBvhStale = true;
     int rc = rebuild_light_trees(c, vertices);
     if (rc != FYPRT_OK) return rc;
@@ -708,13 +795,13 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 12) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 13) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 12) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 13) return FYPRT_EINVAL;
     c->tuning[key] = value;
     return FYPRT_OK;
 }

@@ -1,0 +1,128 @@
+// Device-side builder of the acceleration structure ("GPU LBVH builder + wide-node collapse"; the reference's own
+// abandoned attempt is BVH.cu:1-279 / MortonCode.cuh:11-38).  Selected with tuning key 12 for the next fyprt_upload_scene.
+//   k_lbvh_keys      64-bit sort keys: 30-bit Morton code of the triangle centroid (10 bits per axis over the scene box) in the
+//                    high word, the triangle index in the low word (keys are unique, so the radix tree below is well defined)
+//   (radix sort)     hipcub::DeviceRadixSort::SortKeys
+//   k_lbvh_radix     Karras 2012: one thread per internal node of the binary radix tree over the sorted keys — its key range and
+//                    its two children
+//   k_lbvh_collapse  one BFS level of the collapse into 4-wide nodes: a wide node starts from a binary node's two children and
+//                    keeps replacing the inner child that spans the most triangles by its own two children; a subtree of <= 4
+//                    triangles becomes a leaf (its triangles are consecutive in sorted order = in the leaf-triangle array)
+//   k_lbvh_levels    reverse BFS: levels(node) = 1 + max(levels(inner children)) into the node's meta byte
+// Boxes and their 8-bit quantisation are NOT computed here: the refit pass (rt_refit.h) does that for any topology.
+// Tree quality is that of an LBVH (no SAH): traversal is slower than with the host builder; the build takes milliseconds.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+RT_DEV uint32_t expand_bits10(uint32_t v) {              // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void k_lbvh_keys(const float4* triPos, uint32_t nT, float3 lo, float3 invExt, unsigned long long* keys) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nT) return;
+    const float4* p = triPos + (size_t)t * 3;
+    const float4 a = p[0], b = p[1], c = p[2];
+    const float cx = ((a.x + b.x + c.x) * (1.0f / 3.0f) - lo.x) * invExt.x, cy = ((a.y + b.y + c.y) * (1.0f / 3.0f) - lo.y) * invExt.y,
+                cz = ((a.z + b.z + c.z) * (1.0f / 3.0f) - lo.z) * invExt.z;
+    auto q = [](float v) { v = v * 1024.0f; v = v < 0.0f ? 0.0f : (v > 1023.0f ? 1023.0f : v); return (uint32_t)v; };   // NaN -> 0
+    const uint32_t code = (expand_bits10(q(cx)) << 2) | (expand_bits10(q(cy)) << 1) | expand_bits10(q(cz));
+    keys[t] = ((unsigned long long)code << 32) | t;
+}
+
+// internal node i of the radix tree: range [first, last] of sorted leaves, children (bit 31 set = leaf index)
+struct RadixNode { uint32_t first, last, left, right; };
+constexpr uint32_t kRadixLeaf = 0x80000000u;
+
+RT_DEV int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+__global__ void k_lbvh_radix(const unsigned long long* keys, int n, RadixNode* nodes) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2) if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do { t = (t + 1) >> 1; if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t; } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    RadixNode r; r.first = (uint32_t)lo; r.last = (uint32_t)hi;
+    r.left = (lo == gamma) ? (kRadixLeaf | (uint32_t)gamma) : (uint32_t)gamma;
+    r.right = (hi == gamma + 1) ? (kRadixLeaf | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+    nodes[i] = r;
+}
+
+// leaf-triangle records in sorted order: only the triangle index here, k_refresh_leaf_tris fills in (v0, e1, e2)
+__global__ void k_lbvh_leaf_order(const unsigned long long* keys, uint32_t n, float4* leafTris) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    leafTris[(size_t)j * 3 + 2] = make_float4(0.0f, __int_as_float((int)(uint32_t)(keys[j] & 0xFFFFFFFFull)), 0.0f, 0.0f);
+}
+
+struct CollapseItem { uint32_t radix, wide; };
+
+RT_DEV uint32_t radix_span(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? 1u : rn[ref].last - rn[ref].first + 1u; }
+RT_DEV uint32_t radix_first(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? (ref & ~kRadixLeaf) : rn[ref].first; }
+
+// counters[0]: wide nodes allocated so far; counters[1]: items written to `out`
+__global__ void k_lbvh_collapse(const RadixNode* rn, const CollapseItem* in, uint32_t nIn, CollapseItem* out, uint32_t* counters, float4* nodes) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nIn) return;
+    const CollapseItem it = in[k];
+    uint32_t ch[4]; int cnt = 2;
+    ch[0] = rn[it.radix].left; ch[1] = rn[it.radix].right;
+    while (cnt < 4) {
+        int best = -1; uint32_t bestSpan = 4u;                    // only subtrees of more than 4 triangles are opened
+        for (int i = 0; i < cnt; ++i) { const uint32_t sp = radix_span(rn, ch[i]); if (sp > bestSpan) { bestSpan = sp; best = i; } }
+        if (best < 0) break;
+        const RadixNode b = rn[ch[best]];
+        for (int j = cnt; j > best + 1; --j) ch[j] = ch[j - 1];
+        ch[best] = b.left; ch[best + 1] = b.right; ++cnt;
+    }
+    int32_t ref[4] = {(int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000};
+    for (int i = 0; i < cnt; ++i) {
+        const uint32_t sp = radix_span(rn, ch[i]);
+        if (sp <= 4u) ref[i] = ~(int32_t)((radix_first(rn, ch[i]) << 2) | (sp - 1u));
+        else {
+            const uint32_t w = atomicAdd(counters + 0, 1u);
+            const uint32_t o = atomicAdd(counters + 1, 1u);
+            out[o] = CollapseItem{ch[i], w};
+            ref[i] = (int32_t)w;
+        }
+    }
+    float4* n = nodes + (size_t)it.wide * 4;
+    n[0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float((int)((uint32_t)cnt << 24)));      // boxes + exponents: the refit pass
+    n[1] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
+    n[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); n[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// nodes [first, first + count) of one BFS level, deepest level first
+__global__ void k_lbvh_levels(float4* nodes, uint32_t first, uint32_t count) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float4* n = nodes + (size_t)(first + k) * 4;
+    const float4 q0 = n[0], q1 = n[1];
+    const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u;
+    const int32_t child[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
+    uint32_t below = 0;
+    for (uint32_t i = 0; i < cnt; ++i) if (child[i] >= 0) {
+        const uint32_t cl = ((uint32_t)__float_as_int(nodes[(size_t)child[i] * 4].w)) >> 27;
+        below = cl > below ? cl : below;
+    }
+    const uint32_t levels = 1u + below;
+    n[0].w = __int_as_float((int)((ex & 0x07FFFFFFu) | ((levels > 31u ? 31u : levels) << 27)));
+}
+
+}  // namespace rt

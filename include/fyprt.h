@@ -252,6 +252,10 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        queues shorter than the grid the static part is an even share and no atomic is issued at all).
  * key 11: 1 (default) = wavefront ReSTIR DI frames are pipelined over two streams: Part 1 + setup of frame N+1 run beside the
  *        trace kernel of frame N (asynchronous frames only overlap, of course; a blocking fyprt_render waits for its frame).
+ * key 12: builder of the acceleration structure for the NEXT fyprt_upload_scene: 0 (default) host binned SAH + SAH-optimal
+ *        collapse; 1 device LBVH (Morton sort, Karras radix tree, collapse, refit) — milliseconds instead of a fraction of a
+ *        second for a million triangles, a slower tree to trace; falls back to the host builder if the tree gets deeper than
+ *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties).
  * key 10: smallest chunk of the guided self-scheduling of the shared part: claims shrink from key 4 towards this value as
  *        the queue runs out (default 32).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
