@@ -44,3 +44,17 @@ rebuilt = frame_ms()
 print(json.dumps({"upload_scene_s": round(up, 3), "upload_scene_again_s": round(up2, 3), "update_vertices_s_median": round(float(np.median(ts)), 4),
                   "moved_mesh_triangles": int(sc.meshes[big][1]), "frame_ms_before": round(base, 4), "frame_ms_after_refit": round(refit, 4),
                   "frame_ms_after_rebuild": round(rebuilt, 4)}))
+
+# device builder (tuning key 12) on the same scene: build time and what its tree costs to trace
+ctx2 = capi.Context(0)
+ctx2.resize(W, H)
+ctx2.set_tuning(12, 1)
+tb = []
+for _ in range(3):
+    t = time.perf_counter(); ctx2.upload_scene(sc); tb.append(time.perf_counter() - t)
+ctx2.set_camera(cam)
+ctx = ctx2
+lb = frame_ms()
+b = ctx2.export_bvh()
+print(json.dumps({"device_builder_upload_scene_s": [round(x, 4) for x in tb], "frame_ms_device_built_tree": round(lb, 4), "nodes": int(len(b["nodes"])),
+                  "levels": int(b["max_stack"]), "mean_children": round(float((b["nodes"]["meta"] & 7).mean()), 2)}))
