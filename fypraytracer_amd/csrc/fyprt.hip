@@ -235,20 +235,20 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
     for (uint32_t i = 0; i < nV; ++i) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], verts[i].position[a]); hi[a] = std::max(hi[a], verts[i].position[a]); }
     float3 l3 = make_float3(lo[0], lo[1], lo[2]), ie = make_float3(hi[0] > lo[0] ? 1.0f / (hi[0] - lo[0]) : 0.0f, hi[1] > lo[1] ? 1.0f / (hi[1] - lo[1]) : 0.0f, hi[2] > lo[2] ? 1.0f / (hi[2] - lo[2]) : 0.0f);
     struct Temps {                      // scratch of the build, freed on every way out
-        DevBuf<unsigned long long> keysA, keysB; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
-        ~Temps() { keysA.release(); keysB.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
+        DevBuf<unsigned long long> keysA, keysB; DevBuf<uint32_t> valsA, valsB; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
+        ~Temps() { keysA.release(); keysB.release(); valsA.release(); valsB.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
     } t;
-    auto &keysA = t.keysA, &keysB = t.keysB; auto& radix = t.radix; auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
-    HIPCHK(c, keysA.alloc(nT)); HIPCHK(c, keysB.alloc(nT)); HIPCHK(c, radix.alloc(nT)); HIPCHK(c, qA.alloc(nT)); HIPCHK(c, qB.alloc(nT));
+    auto &keysA = t.keysA, &keysB = t.keysB; auto &valsA = t.valsA, &valsB = t.valsB; auto& radix = t.radix; auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
+    HIPCHK(c, keysA.alloc(nT)); HIPCHK(c, keysB.alloc(nT)); HIPCHK(c, valsA.alloc(nT)); HIPCHK(c, valsB.alloc(nT)); HIPCHK(c, radix.alloc(nT)); HIPCHK(c, qA.alloc(nT)); HIPCHK(c, qB.alloc(nT));
     HIPCHK(c, counters.alloc(2)); HIPCHK(c, wide.alloc((size_t)nT * 4));
-    hipLaunchKernelGGL(k_lbvh_keys, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, nT, l3, ie, keysA.p);
+    hipLaunchKernelGGL(k_lbvh_keys, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, nT, l3, ie, keysA.p, valsA.p);
     size_t tempBytes = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tempBytes, keysA.p, keysB.p, (int)nT, 0, 64, c->stream));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysA.p, keysB.p, valsA.p, valsB.p, (int)nT, 0, 63, c->stream));
     HIPCHK(c, temp.alloc(tempBytes));
-    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(temp.p, tempBytes, keysA.p, keysB.p, (int)nT, 0, 64, c->stream));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp.p, tempBytes, keysA.p, keysB.p, valsA.p, valsB.p, (int)nT, 0, 63, c->stream));
     hipLaunchKernelGGL(k_lbvh_radix, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, (int)nT, radix.p);
     HIPCHK(c, c->leafTris.alloc((size_t)nT * 3));
-    hipLaunchKernelGGL(k_lbvh_leaf_order, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, nT, c->leafTris.p);
+    hipLaunchKernelGGL(k_lbvh_leaf_order, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, valsB.p, nT, c->leafTris.p);
     // BFS collapse, one launch per level; the nodes of a level are contiguous: [levelFirst[l], levelFirst[l + 1])
     const CollapseItem rootItem{0u, 0u};
     uint32_t h_counters[2] = {1u, 0u};

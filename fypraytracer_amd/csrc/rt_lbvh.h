@@ -1,8 +1,8 @@
 // Device-side builder of the acceleration structure ("GPU LBVH builder + wide-node collapse"; the reference's own
 // abandoned attempt is BVH.cu:1-279 / MortonCode.cuh:11-38).  Selected with tuning key 12 for the next fyprt_upload_scene.
-//   k_lbvh_keys      64-bit sort keys: 30-bit Morton code of the triangle centroid (10 bits per axis over the scene box) in the
-//                    high word, the triangle index in the low word (keys are unique, so the radix tree below is well defined)
-//   (radix sort)     hipcub::DeviceRadixSort::SortKeys
+//   k_lbvh_keys      63-bit Morton code of the triangle centroid (21 bits per axis over the scene box) as the sort key, the
+//                    triangle index as the value (equal keys are told apart by their sorted position in the radix tree)
+//   (radix sort)     hipcub::DeviceRadixSort::SortPairs
 //   k_lbvh_radix     Karras 2012: one thread per internal node of the binary radix tree over the sorted keys — its key range and
 //                    its two children
 //   k_lbvh_collapse  one BFS level of the collapse into 4-wide nodes: a wide node starts from a binary node's two children and
@@ -16,31 +16,34 @@
 
 namespace rt {
 
-RT_DEV uint32_t expand_bits10(uint32_t v) {              // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u;
+RT_DEV unsigned long long expand_bits21(unsigned long long v) {   // 21 bits -> every third bit
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull; v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full; v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
-__global__ void k_lbvh_keys(const float4* triPos, uint32_t nT, float3 lo, float3 invExt, unsigned long long* keys) {
+__global__ void k_lbvh_keys(const float4* triPos, uint32_t nT, float3 lo, float3 invExt, unsigned long long* keys, uint32_t* vals) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nT) return;
     const float4* p = triPos + (size_t)t * 3;
     const float4 a = p[0], b = p[1], c = p[2];
     const float cx = ((a.x + b.x + c.x) * (1.0f / 3.0f) - lo.x) * invExt.x, cy = ((a.y + b.y + c.y) * (1.0f / 3.0f) - lo.y) * invExt.y,
                 cz = ((a.z + b.z + c.z) * (1.0f / 3.0f) - lo.z) * invExt.z;
-    auto q = [](float v) { v = v * 1024.0f; v = v < 0.0f ? 0.0f : (v > 1023.0f ? 1023.0f : v); return (uint32_t)v; };   // NaN -> 0
-    const uint32_t code = (expand_bits10(q(cx)) << 2) | (expand_bits10(q(cy)) << 1) | expand_bits10(q(cz));
-    keys[t] = ((unsigned long long)code << 32) | t;
+    auto q = [](float v) { v = v * 2097152.0f; v = v < 0.0f ? 0.0f : (v > 2097151.0f ? 2097151.0f : v); return (unsigned long long)(uint32_t)v; };   // NaN -> 0
+    keys[t] = (expand_bits21(q(cx)) << 2) | (expand_bits21(q(cy)) << 1) | expand_bits21(q(cz));
+    vals[t] = t;
 }
 
 // internal node i of the radix tree: range [first, last] of sorted leaves, children (bit 31 set = leaf index)
 struct RadixNode { uint32_t first, last, left, right; };
 constexpr uint32_t kRadixLeaf = 0x80000000u;
 
-RT_DEV int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {
+RT_DEV int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {     // common prefix; equal keys are told apart by their position
     if (j < 0 || j >= n) return -1;
-    return __clzll((long long)(keys[i] ^ keys[j]));
+    const unsigned long long x = keys[i] ^ keys[j];
+    return x ? __clzll((long long)x) : 64 + __clz(i ^ j);
 }
 
 __global__ void k_lbvh_radix(const unsigned long long* keys, int n, RadixNode* nodes) {
@@ -65,10 +68,10 @@ __global__ void k_lbvh_radix(const unsigned long long* keys, int n, RadixNode* n
 }
 
 // leaf-triangle records in sorted order: only the triangle index here, k_refresh_leaf_tris fills in (v0, e1, e2)
-__global__ void k_lbvh_leaf_order(const unsigned long long* keys, uint32_t n, float4* leafTris) {
+__global__ void k_lbvh_leaf_order(const uint32_t* vals, uint32_t n, float4* leafTris) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    leafTris[(size_t)j * 3 + 2] = make_float4(0.0f, __int_as_float((int)(uint32_t)(keys[j] & 0xFFFFFFFFull)), 0.0f, 0.0f);
+    leafTris[(size_t)j * 3 + 2] = make_float4(0.0f, __int_as_float((int)vals[j]), 0.0f, 0.0f);
 }
 
 struct CollapseItem { uint32_t radix, wide; };
