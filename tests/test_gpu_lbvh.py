@@ -52,3 +52,52 @@ def test_device_built_tree(oracle_built, name):
     ctx.render(st); host.render(st)
     assert bits_equal(ctx.readback()[1], host.readback()[1]).all(axis=-1).mean() > 0.97
     ctx.close(); host.close()
+
+
+@pytest.mark.parametrize("shape", ["nested", "exponential", "coincident"])
+def test_device_builder_on_pathological_input(oracle_built, shape):
+    """Inputs that make a radix tree deep or degenerate: nested triangles sharing a corner, exponentially shrinking spacing (the
+    Morton prefix changes at every level: the builder must fall back to the host one beyond 31 wide levels), many triangles
+    with one and the same centroid (equal keys, told apart by position).  Whatever builder ends up being used, the exported
+    tree must be valid and the picture must equal the oracle's over that tree."""
+    from oraclelib import Oracle
+    from fypraytracer_amd.scene import Material, Scene
+    from fypraytracer_amd import scenes
+    if shape == "nested":
+        n = 3000
+        s = 0.999 ** np.arange(n, dtype=np.float64)
+        pos = np.zeros((n * 3, 3), dtype=np.float32); pos[1::3, 0] = s; pos[2::3, 1] = s
+    elif shape == "exponential":
+        n = 480
+        x = (2.0 ** -(np.arange(n, dtype=np.float64) * 0.25)).astype(np.float32)
+        pos = np.zeros((n * 3, 3), dtype=np.float32)
+        pos[0::3, 0] = x; pos[1::3, 0] = x * 1.01; pos[2::3, 0] = x; pos[2::3, 1] = x * 0.01
+    else:
+        n = 600
+        rng = np.random.default_rng(11)
+        d = rng.normal(size=(n, 3)).astype(np.float32) * 0.3
+        pos = np.zeros((n * 3, 3), dtype=np.float32)
+        pos[0::3] = d; pos[1::3] = -d * 0.5 + np.roll(d, 1, axis=1) * 0.5; pos[2::3] = -(pos[0::3] + pos[1::3])   # centroid = origin for all
+    sc = Scene()
+    sc.materials = [Material(albedo=(0.8, 0.8, 0.8))]
+    sc.add_new_mesh_to_scene(pos, np.tile(np.array([0, 0, 1], np.float32), (n * 3, 1)), np.zeros((n * 3, 2), np.float32),
+                             np.arange(n * 3, dtype=np.uint32).reshape(-1, 3), material_index=0)
+    W, H = 64, 48
+    cam = scenes.cornell_camera(W, H)
+    cam.set_position((0.3, 0.2, 2.5))
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.set_tuning(12, 1)
+    ctx.upload_scene(sc)
+    ctx.set_camera(cam)
+    bvh = ctx.export_bvh()
+    check_bvh_invariants(bvh, sc, require_wide=False)
+    assert bvh["max_stack"] <= 31 and ctx.get_tuning(8) >= bvh["max_stack"]
+    orc = Oracle(sc, W, H)
+    orc.set_camera(cam)
+    orc.use_product_bvh(bvh)
+    st = settings_for(capi.COSINE_WEIGHTED_SAMPLING)
+    ctx.render(st); orc.render(st)
+    img, acc = ctx.readback()
+    assert bits_equal(acc, orc.accum()).all() and np.array_equal(img, orc.image())
+    ctx.close()
