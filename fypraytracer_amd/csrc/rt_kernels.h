@@ -6,6 +6,21 @@
 #pragma once
 #include "rt_device.h"
 
+// Register budgets of the fat one-thread-per-pixel kernels: the compiler's own allocation leaves the light-tree kernels at 2 waves
+// per SIMD (171-184 VGPRs); capping them at the budget of 4 waves (128 VGPRs, a few spills) is 1.45x faster (7.5 -> 5.2 ms for
+// config 3; 3, 5 and 6 waves measured too: 5.8 / 5.4 / 6.4 ms).
+#ifndef RT_NEE_WAVES
+#define RT_NEE_WAVES __attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
+// The path and ReSTIR GI kernels (95-155 and 114 VGPRs) likewise: capped at the budget of 7 waves (72 VGPRs) — which is also what
+// the 22 KB LDS stack lets a CU hold — 4K ReSTIR GI 15.8 -> 13.6 ms, cosine 4 spp 1.36 -> 1.18 ms, BRDF sampling on the 1M-triangle
+// scene 2.79 -> 2.08 ms (5 / 6 / 8 waves: 14.6 / 13.8 / 14.2 ms for GI).
+#ifndef RT_GI_WAVES
+#define RT_GI_WAVES __attribute__((amdgpu_waves_per_eu(7, 8)))
+#endif
+#ifndef RT_PATH_WAVES
+#define RT_PATH_WAVES __attribute__((amdgpu_waves_per_eu(7, 8)))
+#endif
 namespace rt {
 
 enum Tech { T_BRUTE = 0, T_UNIFORM = 1, T_COSINE = 2, T_GGX = 3, T_BRDF = 4, T_LIGHT = 5, T_NEE = 6, T_DI = 7, T_GI = 8 };
@@ -73,7 +88,7 @@ RT_DEV f3 sample_dir(f3 n, f3 V, const Mat& m, f3 albedo, float ggxRoughness, ui
 }
 
 template <int TECH>
-__global__ __launch_bounds__(kBlock) void k_path(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+__global__ __launch_bounds__(kBlock) RT_PATH_WAVES void k_path(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
@@ -198,7 +213,7 @@ RT_DEV float direct_emitter_pmf(const DevScene& sc, f3 spPos, uint32_t emitterTr
 }
 
 // ============================================================ LIGHT_SOURCE_SAMPLING (Renderer.cu:1287-1408)
-__global__ __launch_bounds__(kBlock) void k_light_source(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+__global__ __launch_bounds__(kBlock) RT_NEE_WAVES void k_light_source(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_light_source(DevScene sc, DevCamera 
 }
 
 // ============================================================ NEE (Renderer.cu:1411-1626)
-__global__ __launch_bounds__(kBlock) void k_nee(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+__global__ __launch_bounds__(kBlock) RT_NEE_WAVES void k_nee(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
@@ -502,7 +517,7 @@ RT_DEV void gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {     
 }
 RT_DEV f3 lo3(const GISample& s) { return mk3(s.Lo[0], s.Lo[1], s.Lo[2]); }
 
-__global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
+__global__ __launch_bounds__(kBlock) RT_GI_WAVES void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!p1_pixel_of_thread(fr, p1Begin, p1End, extraRow, x, y)) return;
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_gi_part1(DevScene sc, DevCamera cam,
     if (inBand) fr.image[i] = 0u;
 }
 
-__global__ __launch_bounds__(kBlock) void k_gi_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
+__global__ __launch_bounds__(kBlock) RT_GI_WAVES void k_gi_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
     if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
