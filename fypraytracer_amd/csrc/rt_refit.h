@@ -47,7 +47,7 @@ RT_DEV void rbox_grow(RBox& b, float x, float y, float z) {
 }
 
 // nodeBox: 2 float4 per node (lo.xyz, hi.xyz), written for every node processed
-__global__ void k_refit_level(float4* nodes, const uint32_t* levelNodes, uint32_t count, const float4* leafTris, const float4* triPos, float4* nodeBox) {
+__global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32_t* levelNodes, uint32_t count, const float4* leafTris, const float4* triPos, float4* nodeBox) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     const uint32_t node = levelNodes[k];
