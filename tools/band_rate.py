@@ -17,18 +17,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--technique", type=int, default=7)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--all-ranks", action="store_true", help="every band of each split instead of one interior band")
     a = ap.parse_args()
-    W, H = 1920, 1080
+    W, H = a.width, a.height
     sc, cam = scenes.hall_scene(), scenes.hall_camera(W, H)
     ctx = capi.Context(0)
     ctx.resize(W, H)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
-    st = capi.Settings(technique=capi.RESTIR_DI, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
+    st = capi.Settings(technique=a.technique, light_bounces=1 if a.technique == 7 else 2, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
     for n, rank in [(n, r) for n in a.n for r in (range(n) if a.all_ranks else [n // 2 if n > 1 else 0])]:   # default: an interior band (two halos)
         y0, y1 = multigpu.band_rows(H, n, rank)
-        ctx.set_rows(y0, y1, multigpu.halo_rows(st, capi.RESTIR_DI, n))
+        ctx.set_rows(y0, y1, multigpu.halo_rows(st, a.technique, n))
         ctx.reset_frame_index()
         for f in range(10):
             st.rand_seed = f + 1
