@@ -235,10 +235,12 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
     for (uint32_t i = 0; i < nV; ++i) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], verts[i].position[a]); hi[a] = std::max(hi[a], verts[i].position[a]); }
     float3 l3 = make_float3(lo[0], lo[1], lo[2]), ie = make_float3(hi[0] > lo[0] ? 1.0f / (hi[0] - lo[0]) : 0.0f, hi[1] > lo[1] ? 1.0f / (hi[1] - lo[1]) : 0.0f, hi[2] > lo[2] ? 1.0f / (hi[2] - lo[2]) : 0.0f);
     struct Temps {                      // scratch of the build, freed on every way out
-        DevBuf<unsigned long long> keysA, keysB; DevBuf<uint32_t> valsA, valsB; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
-        ~Temps() { keysA.release(); keysB.release(); valsA.release(); valsB.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
+        DevBuf<unsigned long long> keysA, keysB; DevBuf<uint32_t> valsA, valsB, parentOfNode, parentOfLeaf, arrived; DevBuf<float> box; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
+        ~Temps() { keysA.release(); keysB.release(); valsA.release(); valsB.release(); parentOfNode.release(); parentOfLeaf.release(); arrived.release(); box.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
     } t;
-    auto &keysA = t.keysA, &keysB = t.keysB; auto &valsA = t.valsA, &valsB = t.valsB; auto& radix = t.radix; auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
+    auto &keysA = t.keysA, &keysB = t.keysB; auto &valsA = t.valsA, &valsB = t.valsB; auto& radix = t.radix;
+    HIPCHK(c, t.parentOfNode.alloc(nT)); HIPCHK(c, t.parentOfLeaf.alloc(nT)); HIPCHK(c, t.arrived.alloc(nT)); HIPCHK(c, t.box.alloc((size_t)nT * 6));
+    HIPCHK(c, hipMemsetAsync(t.arrived.p, 0, (size_t)nT * 4, c->stream)); auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
     HIPCHK(c, keysA.alloc(nT)); HIPCHK(c, keysB.alloc(nT)); HIPCHK(c, valsA.alloc(nT)); HIPCHK(c, valsB.alloc(nT)); HIPCHK(c, radix.alloc(nT)); HIPCHK(c, qA.alloc(nT)); HIPCHK(c, qB.alloc(nT));
     HIPCHK(c, counters.alloc(2)); HIPCHK(c, wide.alloc((size_t)nT * 4));
     hipLaunchKernelGGL(k_lbvh_keys, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, nT, l3, ie, keysA.p, valsA.p);
@@ -246,7 +248,8 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysA.p, keysB.p, valsA.p, valsB.p, (int)nT, 0, 63, c->stream));
     HIPCHK(c, temp.alloc(tempBytes));
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp.p, tempBytes, keysA.p, keysB.p, valsA.p, valsB.p, (int)nT, 0, 63, c->stream));
-    hipLaunchKernelGGL(k_lbvh_radix, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, (int)nT, radix.p);
+    hipLaunchKernelGGL(k_lbvh_radix, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, (int)nT, radix.p, t.parentOfNode.p, t.parentOfLeaf.p);
+    hipLaunchKernelGGL(k_lbvh_boxes, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, radix.p, t.parentOfNode.p, t.parentOfLeaf.p, valsB.p, c->triPos.p, nT, t.arrived.p, t.box.p);
     HIPCHK(c, c->leafTris.alloc((size_t)nT * 3));
     hipLaunchKernelGGL(k_lbvh_leaf_order, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, valsB.p, nT, c->leafTris.p);
     // BFS collapse, one launch per level; the nodes of a level are contiguous: [levelFirst[l], levelFirst[l + 1])
@@ -258,7 +261,7 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
     uint32_t nIn = 1, total = 1;
     CollapseItem *in = qA.p, *out = qB.p;
     while (nIn) {
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3((nIn + 127u) / 128u), dim3(128), 0, c->stream, radix.p, in, nIn, out, counters.p, wide.p);
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3((nIn + 127u) / 128u), dim3(128), 0, c->stream, radix.p, t.box.p, in, nIn, out, counters.p, wide.p);
         HIPCHK(c, hipMemcpyAsync(h_counters, counters.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         levelFirst.push_back(total);

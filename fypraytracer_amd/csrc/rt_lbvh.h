@@ -5,8 +5,9 @@
 //   (radix sort)     hipcub::DeviceRadixSort::SortPairs
 //   k_lbvh_radix     Karras 2012: one thread per internal node of the binary radix tree over the sorted keys — its key range and
 //                    its two children
+//   k_lbvh_boxes     boxes of the radix tree's nodes, bottom-up (second arrival at a node unites its children's boxes)
 //   k_lbvh_collapse  one BFS level of the collapse into 4-wide nodes: a wide node starts from a binary node's two children and
-//                    keeps replacing the inner child that spans the most triangles by its own two children; a subtree of <= 4
+//                    keeps replacing the inner child of largest surface area by its own two children; a subtree of <= 4
 //                    triangles becomes a leaf (its triangles are consecutive in sorted order = in the leaf-triangle array)
 //   k_lbvh_levels    reverse BFS: levels(node) = 1 + max(levels(inner children)) into the node's meta byte
 // Boxes and their 8-bit quantisation are NOT computed here: the refit pass (rt_refit.h) does that for any topology.
@@ -46,7 +47,7 @@ RT_DEV int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {    
     return x ? __clzll((long long)x) : 64 + __clz(i ^ j);
 }
 
-__global__ void k_lbvh_radix(const unsigned long long* keys, int n, RadixNode* nodes) {
+__global__ void k_lbvh_radix(const unsigned long long* keys, int n, RadixNode* nodes, uint32_t* parentOfNode, uint32_t* parentOfLeaf) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n - 1) return;
     const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -65,6 +66,36 @@ __global__ void k_lbvh_radix(const unsigned long long* keys, int n, RadixNode* n
     r.left = (lo == gamma) ? (kRadixLeaf | (uint32_t)gamma) : (uint32_t)gamma;
     r.right = (hi == gamma + 1) ? (kRadixLeaf | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
     nodes[i] = r;
+    if (r.left & kRadixLeaf) parentOfLeaf[r.left & ~kRadixLeaf] = (uint32_t)i; else parentOfNode[r.left] = (uint32_t)i;
+    if (r.right & kRadixLeaf) parentOfLeaf[r.right & ~kRadixLeaf] = (uint32_t)i; else parentOfNode[r.right] = (uint32_t)i;
+}
+
+// boxes of the radix tree's internal nodes, bottom-up: every leaf walks towards the root, the second thread to arrive at a node
+// (its sibling subtree is complete then) unites the two child boxes and goes on.  box[i] = {lo.xyz, hi.xyz}.
+RT_DEV void lbvh_leaf_box(const float4* triPos, uint32_t tri, float* b) {
+    const float4* p = triPos + (size_t)tri * 3;
+    const float4 a = p[0], bb = p[1], c = p[2];
+    b[0] = __builtin_fminf(a.x, __builtin_fminf(bb.x, c.x)); b[1] = __builtin_fminf(a.y, __builtin_fminf(bb.y, c.y)); b[2] = __builtin_fminf(a.z, __builtin_fminf(bb.z, c.z));
+    b[3] = __builtin_fmaxf(a.x, __builtin_fmaxf(bb.x, c.x)); b[4] = __builtin_fmaxf(a.y, __builtin_fmaxf(bb.y, c.y)); b[5] = __builtin_fmaxf(a.z, __builtin_fmaxf(bb.z, c.z));
+}
+__global__ void k_lbvh_boxes(const RadixNode* rn, const uint32_t* parentOfNode, const uint32_t* parentOfLeaf, const uint32_t* vals, const float4* triPos,
+                             uint32_t n, uint32_t* arrived, float* box) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t cur = parentOfLeaf[j];
+    while (true) {
+        __threadfence();
+        if (atomicAdd(arrived + cur, 1u) == 0u) return;            // the sibling subtree is not done yet: its thread will do this node
+        __threadfence();
+        const RadixNode r = rn[cur];
+        float a[6], b[6];
+        if (r.left & kRadixLeaf) lbvh_leaf_box(triPos, vals[r.left & ~kRadixLeaf], a); else for (int k = 0; k < 6; ++k) a[k] = __hip_atomic_load(box + (size_t)r.left * 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r.right & kRadixLeaf) lbvh_leaf_box(triPos, vals[r.right & ~kRadixLeaf], b); else for (int k = 0; k < 6; ++k) b[k] = __hip_atomic_load(box + (size_t)r.right * 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 3; ++k) { __hip_atomic_store(box + (size_t)cur * 6 + k, __builtin_fminf(a[k], b[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                      __hip_atomic_store(box + (size_t)cur * 6 + 3 + k, __builtin_fmaxf(a[3 + k], b[3 + k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (cur == 0u) return;
+        cur = parentOfNode[cur];
+    }
 }
 
 // leaf-triangle records in sorted order: only the triangle index here, k_refresh_leaf_tris fills in (v0, e1, e2)
@@ -80,15 +111,20 @@ RT_DEV uint32_t radix_span(const RadixNode* rn, uint32_t ref) { return (ref & kR
 RT_DEV uint32_t radix_first(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? (ref & ~kRadixLeaf) : rn[ref].first; }
 
 // counters[0]: wide nodes allocated so far; counters[1]: items written to `out`
-__global__ void k_lbvh_collapse(const RadixNode* rn, const CollapseItem* in, uint32_t nIn, CollapseItem* out, uint32_t* counters, float4* nodes) {
+RT_DEV float lbvh_area(const float* box, uint32_t node) {
+    const float* b = box + (size_t)node * 6;
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const CollapseItem* in, uint32_t nIn, CollapseItem* out, uint32_t* counters, float4* nodes) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nIn) return;
     const CollapseItem it = in[k];
     uint32_t ch[4]; int cnt = 2;
     ch[0] = rn[it.radix].left; ch[1] = rn[it.radix].right;
     while (cnt < 4) {
-        int best = -1; uint32_t bestSpan = 4u;                    // only subtrees of more than 4 triangles are opened
-        for (int i = 0; i < cnt; ++i) { const uint32_t sp = radix_span(rn, ch[i]); if (sp > bestSpan) { bestSpan = sp; best = i; } }
+        int best = -1; float bestArea = -1.0f;                    // the child of largest surface area among those of more than 4 triangles
+        for (int i = 0; i < cnt; ++i) if (radix_span(rn, ch[i]) > 4u) { const float ar = lbvh_area(box, ch[i]); if (ar > bestArea) { bestArea = ar; best = i; } }
         if (best < 0) break;
         const RadixNode b = rn[ch[best]];
         for (int j = cnt; j > best + 1; --j) ch[j] = ch[j - 1];
