@@ -106,6 +106,10 @@ __global__ void k_lbvh_leaf_order(const uint32_t* vals, uint32_t n, float4* leaf
 }
 
 struct CollapseItem { uint32_t radix, wide; };
+#ifndef RT_LBVH_LEAF
+#define RT_LBVH_LEAF 4u
+#endif
+constexpr uint32_t kLbvhLeaf = RT_LBVH_LEAF;      // a radix subtree of at most this many triangles becomes one leaf
 
 RT_DEV uint32_t radix_span(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? 1u : rn[ref].last - rn[ref].first + 1u; }
 RT_DEV uint32_t radix_first(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? (ref & ~kRadixLeaf) : rn[ref].first; }
@@ -124,7 +128,7 @@ __global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const Col
     ch[0] = rn[it.radix].left; ch[1] = rn[it.radix].right;
     while (cnt < 4) {
         int best = -1; float bestArea = -1.0f;                    // the child of largest surface area among those of more than 4 triangles
-        for (int i = 0; i < cnt; ++i) if (radix_span(rn, ch[i]) > 4u) { const float ar = lbvh_area(box, ch[i]); if (ar > bestArea) { bestArea = ar; best = i; } }
+        for (int i = 0; i < cnt; ++i) if (radix_span(rn, ch[i]) > kLbvhLeaf) { const float ar = lbvh_area(box, ch[i]); if (ar > bestArea) { bestArea = ar; best = i; } }
         if (best < 0) break;
         const RadixNode b = rn[ch[best]];
         for (int j = cnt; j > best + 1; --j) ch[j] = ch[j - 1];
@@ -133,7 +137,7 @@ __global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const Col
     int32_t ref[4] = {(int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000};
     for (int i = 0; i < cnt; ++i) {
         const uint32_t sp = radix_span(rn, ch[i]);
-        if (sp <= 4u) ref[i] = ~(int32_t)((radix_first(rn, ch[i]) << 2) | (sp - 1u));
+        if (sp <= kLbvhLeaf) ref[i] = ~(int32_t)((radix_first(rn, ch[i]) << 2) | (sp - 1u));
         else {
             const uint32_t w = atomicAdd(counters + 0, 1u);
             const uint32_t o = atomicAdd(counters + 1, 1u);
