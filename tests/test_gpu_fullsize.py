@@ -81,6 +81,25 @@ def test_restir_di_1080p_ray_accounting(hall):
     ctx.close()
 
 
+def test_restir_di_1080p_frame_time_sanity(hall):
+    """Not a benchmark (bench.py is): a loose ceiling that catches a gross performance regression the bit-exact tests cannot
+    see — e.g. a launch parameter dropped in a refactor.  The north-star target is 4.15 ms per frame; this build renders the
+    frame in about 1.1 ms (blocking)."""
+    W, H = 1920, 1080
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.upload_scene(hall)
+    ctx.set_camera(scenes.hall_camera(W, H))
+    st = settings_for(capi.RESTIR_DI)
+    ks = []
+    for f in range(12):
+        st.rand_seed = f + 1
+        ks.append(ctx.render(st).kernel_ms)
+    assert float(np.median(ks[4:])) < 2.0, ks
+    assert ctx.get_tuning(2) >= 4                            # the persistent trace kernel really is resident several times per CU
+    ctx.close()
+
+
 def test_restir_gi_4k_is_deterministic(hall):
     W, H = 3840, 2160
     cam = scenes.hall_camera(W, H)
