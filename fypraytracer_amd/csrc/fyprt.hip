@@ -547,7 +547,9 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
-    c->dsc.nodeQuorum = (uint32_t)c->tuning[7];                 // 0 by default: measured best for every fused per-pixel kernel
+    // node-loop quorum of the fused per-pixel kernels (key 7): 0 = auto — 16 for the light-tree kernels (their shadow rays: NEE 5.2 -> 4.95 ms),
+    // none elsewhere (path and ReSTIR GI kernels: neutral or slightly negative)
+    c->dsc.nodeQuorum = c->tuning[7] > 0 ? (uint32_t)c->tuning[7] : ((tech == FYPRT_NEE || tech == FYPRT_LIGHT_SOURCE_SAMPLING) ? 16u : 0u);
     // traversal-stack budget (node_step's rule): never below the level count (the induction), never above the 31 the node
     // format records; by default a few entries above the level count, so the LDS stack is no larger than this tree needs
     // and more workgroups fit a CU (LDS is what limits residency: (budget + 1) KB per 256-thread workgroup)
