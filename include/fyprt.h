@@ -240,34 +240,34 @@ int fyprt_export_lighttrees(fyprt_context* ctx, fyprt_lighttree_node* tlas, uint
 /* Count rays / box tests / triangle tests on the device (atomics; slows the frame); off by default. */
 int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
 
-/* Performance knobs that never change results (A/B experiments; defaults are the measured best).
+/* Performance knobs (A/B experiments; defaults are the measured best).  Keys 0-7, 9-11 never change a result; keys 8 and 12
+ * change the traversal order / the tree and with it only which of two triangles hit at EXACTLY the same t wins.
  * key 0: tile order — 0 linear, 1 one contiguous eighth of the tiles per XCD, 2 every 8th tile row per XCD.
  * key 1: ReSTIR DI Part 2 — 0 one thread per pixel, 1 setup kernel + shadow-task queue + persistent trace waves.
- * key 2: persistent workgroups per CU for the trace kernel (default 0 = as many as LDS and registers allow, at most 5).
+ * key 2: persistent workgroups per CU for the trace kernel (default 0 = as many as LDS and registers allow: 6 today).
  * key 3: 1 = counting-sort the shadow tasks by light bin before tracing (slotted tasks + histogram matrix + column scan +
  *        scatter, no global atomics).  Default 0: measured +0.04 ms for the sort and no faster trace — shadow-ray cost is
  *        dominated by the geometry around the ray ORIGIN, which the unsorted tile order already keeps coherent.
  * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
+ * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
+ * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
+ *        fewer than this many lanes are still walking inner nodes (default 24; 0 = classic while-while).
+ * key 7: the same for every other kernel (default 0 = 16 for the light-source / NEE kernels, none elsewhere: measured
+ *        neutral or slightly negative there).
+ * key 8: pending-entry budget of the traversal stack rule (default 0 = a few entries above the tree's level count, chosen
+ *        so that one more workgroup fits a CU's LDS; at most 31; always clamped from below to the tree's level count):
+ *        siblings are pushed one by one while pending + 2 + levels(node) <= budget, else as one resume entry; the LDS stack holds budget + 1 entries per thread.
+ *        Unlike keys 0-7 the value can change the visiting order (exact-t ties may resolve differently).
  * key 9: chunks every persistent wave owns statically before it starts stealing from the shared head (default 1; on
  *        queues shorter than the grid the static part is an even share and no atomic is issued at all).
+ * key 10: smallest chunk of the guided self-scheduling of the shared part: claims shrink from key 4 towards this value as
+ *        the queue runs out (default 32).
  * key 11: 1 (default) = wavefront ReSTIR DI frames are pipelined over two streams: Part 1 + setup of frame N+1 run beside the
  *        trace kernel of frame N (asynchronous frames only overlap, of course; a blocking fyprt_render waits for its frame).
  * key 12: builder of the acceleration structure for the NEXT fyprt_upload_scene: 0 (default) host binned SAH + SAH-optimal
  *        collapse; 1 device LBVH (Morton sort, Karras radix tree, collapse, refit) — milliseconds instead of a fraction of a
  *        second for a million triangles, a slower tree to trace; falls back to the host builder if the tree gets deeper than
- *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties).
- * key 10: smallest chunk of the guided self-scheduling of the shared part: claims shrink from key 4 towards this value as
- *        the queue runs out (default 32).
- * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
- * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
- *        fewer than this many lanes are still walking inner nodes (default 16; 0 = classic while-while).
- * key 7: the same for every other kernel (default 0 = 16 for the light-source / NEE kernels, none elsewhere: measured
- *        neutral or slightly negative there).
- * key 8: pending-entry budget of the traversal stack rule (default 0 = a few entries above the tree's level count, chosen
- *        so that one more workgroup fits a CU's LDS; at most 31; always clamped from below to the tree's level count):
- *        siblings are pushed one by one while
- *        pending + 2 + levels(node) <= budget, else as one resume entry; the LDS stack holds budget + 1 entries per thread.
- *        Unlike keys 0-7 the value can change the visiting order (exact-t ties may resolve differently). */
+ *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
  * traversal must use too). */
