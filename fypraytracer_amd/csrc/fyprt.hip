@@ -52,6 +52,7 @@ struct fyprt_context {
     static constexpr int kRing = 128;          // frames whose per-launch hipEvents are kept (fyprt_frame_timings)
     hipEvent_t ring[kRing][5] = {}; int ringLaunches[kRing] = {}; unsigned long long frameSerial = 0; hipEvent_t* ev = nullptr;
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
+    uint32_t histDI[2] = {0, 0}, histGI[2] = {0, 0};   // rows [begin, end) whose ReSTIR DI / GI history this context holds (the band of the last such frame)
     bool haveScene = false, haveCamera = false, countRays = false;
     // per-pixel buffers
     DevBuf<float4> accum; DevBuf<uint32_t> image; DevBuf<Payload> payload; DevBuf<float> depth; DevBuf<f2> normalA, normalB;
@@ -71,6 +72,7 @@ struct fyprt_context {
     rth::SceneBVH hostBvh; rth::LightTrees hostLt; uint32_t meshCount = 0;
     int lastLaunches = 0;
     size_t queueStride = 0;                     // float4s per task queue
+    size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
     int tuning[13] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
@@ -184,8 +186,11 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
         const size_t maxGroups = std::max(tilesX * ((tilesY + 7u) / 8u) * 8u, ((tilesX * tilesY + 7u) / 8u) * 8u);
         HIPCHK(c, c->shadowTasks.alloc((size_t)maxGroups * 256u * 4u * 2u));   // two queues (frame parity) of 64-byte tasks
         c->queueStride = (size_t)maxGroups * 256u * 4u;
-        HIPCHK(c, c->sortCounts.alloc(maxGroups)); HIPCHK(c, c->sortKeys.alloc(maxGroups * 256u)); HIPCHK(c, c->sortHist.alloc(maxGroups * kSortBins));
-        HIPCHK(c, c->sortOffset.alloc(maxGroups * kSortBins)); HIPCHK(c, c->sortTotal.alloc(kSortBins)); HIPCHK(c, c->sortIndex.alloc(maxGroups * 256u));
+        // the sort scratch alternates with the frame parity like the queues: frame N+1's setup / scan / scatter (front stream) run
+        // beside frame N's trace kernel, which still reads its `sorted` index
+        c->sortGroups = maxGroups;
+        HIPCHK(c, c->sortCounts.alloc(2 * maxGroups)); HIPCHK(c, c->sortKeys.alloc(2 * maxGroups * 256u)); HIPCHK(c, c->sortHist.alloc(2 * maxGroups * kSortBins));
+        HIPCHK(c, c->sortOffset.alloc(2 * maxGroups * kSortBins)); HIPCHK(c, c->sortTotal.alloc(2 * kSortBins)); HIPCHK(c, c->sortIndex.alloc(2 * maxGroups * 256u));
     }
     // cudaMemset(…, 0, …) of every buffer: Renderer.cu:333-355, :372, :393, :414
     HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->image.p, 0, c->image.bytes(), c->stream));
@@ -195,6 +200,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemsetAsync(c->gi.p, 0, c->gi.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->giPrev.p, 0, c->giPrev.bytes(), c->stream));
     HIPCHK(c, sync_all(c));
     c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->externalImage = nullptr;
+    c->histDI[0] = c->histGI[0] = 0; c->histDI[1] = c->histGI[1] = h;        // zero-filled history: "valid" everywhere, M = 0
     if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
     return FYPRT_OK;
 }
@@ -546,6 +552,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p;
     fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
+    fr.histBegin = (tech == FYPRT_RESTIR_GI) ? c->histGI[0] : c->histDI[0]; fr.histEnd = (tech == FYPRT_RESTIR_GI) ? c->histGI[1] : c->histDI[1];
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
     // node-loop quorum of the fused per-pixel kernels (key 7): 0 = auto — 16 for the light-tree kernels (their shadow rays: NEE 5.2 -> 4.95 ms),
     // none elsewhere (path and ReSTIR GI kernels: neutral or slightly negative)
@@ -615,8 +622,9 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 ShadowQueue q{};
                 q.tasks = c->shadowTasks.p + (size_t)par * c->queueStride; q.counters = c->queueCounters.p + 4 * par;
                 q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24); q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
-                q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p; q.keys = c->sortKeys.p; q.hist = c->sortHist.p;
-                q.binOffset = c->sortOffset.p; q.binTotal = c->sortTotal.p; q.sorted = c->sortIndex.p;
+                const size_t sg = (size_t)par * c->sortGroups;
+                q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p + sg; q.keys = c->sortKeys.p + sg * 256u; q.hist = c->sortHist.p + sg * kSortBins;
+                q.binOffset = c->sortOffset.p + sg * kSortBins; q.binTotal = c->sortTotal.p + (size_t)par * kSortBins; q.sorted = c->sortIndex.p + sg * 256u;
                 HIPCHK(c, hipMemsetAsync(q.counters, 0, 16, fs));
                 hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, fs, c->dsc, c->dcam, fr, st, q);
                 if (q.sortMode) {
@@ -644,7 +652,8 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             }
             else if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
             else hipLaunchKernelGGL(k_gi_part2, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
-            if (tech == FYPRT_RESTIR_DI) c->dprevFlip = !c->dprevFlip; else c->normalFlip = !c->normalFlip;
+            if (tech == FYPRT_RESTIR_DI) { c->dprevFlip = !c->dprevFlip; c->histDI[0] = c->rowBegin; c->histDI[1] = c->rowEnd; }
+            else { c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd; }
             break;
         }
     }
@@ -807,6 +816,12 @@ int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
     if (!c || key < 0 || key >= 13) return FYPRT_EINVAL;
+    // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
+    // refilled) or index past a buffer, so it is refused here instead of trusted
+    static const int lo[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int hi[13] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1};
+    if (value < lo[key] || value > hi[key])
+        return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;
     return FYPRT_OK;
 }

@@ -365,7 +365,8 @@ RT_DEV float di_target(const DevScene& sc, uint32_t emissiveSlot, const Payload&
     return length(Lr);
 }
 RT_DEV int f2i_sat(float f) { if (!(f == f)) return 0; if (f >= 2147483520.0f) return 2147483647; if (f <= -2147483648.0f) return (-2147483647 - 1); return (int)f; }
-RT_DEV uint32_t prev_pixel(const DevCamera& cam, f3 wp) {                                   // Renderer.cu:1750-1763
+// `row` = the reprojected pixel's row: a row band only holds history of the rows it rendered last frame (DevFrame::histBegin/End)
+RT_DEV uint32_t prev_pixel(const DevCamera& cam, f3 wp, uint32_t& row) {                    // Renderer.cu:1750-1763
     const f4 clip = mul(cam.prevProjView, mk4(wp.x, wp.y, wp.z, 1.0f));
     float nx = 0.0f, ny = 0.0f;
     if (clip.w != 0.0f) { nx = clip.x / clip.w; ny = clip.y / clip.w; }
@@ -373,6 +374,7 @@ RT_DEV uint32_t prev_pixel(const DevCamera& cam, f3 wp) {                       
     int px = f2i_sat(__builtin_floorf(sx)), py = f2i_sat(__builtin_floorf(sy));
     px = px < 0 ? 0 : (px > (int)cam.W - 1 ? (int)cam.W - 1 : px);
     py = py < 0 ? 0 : (py > (int)cam.H - 1 ? (int)cam.H - 1 : py);
+    row = (uint32_t)py;
     return (uint32_t)py * cam.W + (uint32_t)px;
 }
 RT_DEV uint32_t neighbor_index(const DevCamera& cam, uint32_t W, uint32_t x, uint32_t y, uint32_t radius, uint32_t& seed) {   // :1915-1922
@@ -424,12 +426,15 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
     }
     R.W = R.pdf > 0.0f ? ((1.0f / R.pdf) * R.wSum) / (float)R.M : 0.0f;
     if (st.useTemporal) {
-        const uint32_t prevIdx = prev_pixel(cam, pos3(pp));
+        uint32_t prow;
+        const uint32_t prevIdx = prev_pixel(cam, pos3(pp), prow);
         const DIRec prec = load_rec(fr.dprevRead + prevIdx);
         f2 pn; pn.x = prec.nx; pn.y = prec.ny;
         const f3 prevN = oct_decode(pn);
         DIRes prev = rec_reservoir(prec);
-        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99;
+        // history exists only for the rows this context rendered last frame (the whole frame unless fyprt_set_rows split it), and a
+        // history light index must exist in the CURRENT emissive list (the scene may have been replaced: DESIGN.md §5 R7)
+        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99 && prow >= fr.histBegin && prow < fr.histEnd && prev.index < nE;
         if (valid && prev.M > 0u) {
             const uint32_t lim = st.historyLimit * R.M;
             prev.M = (lim < prev.M) ? lim : prev.M;
@@ -579,10 +584,11 @@ __global__ __launch_bounds__(kBlock) RT_GI_WAVES void k_gi_part1(DevScene sc, De
         R.W = R.s.pdf > 0.0f ? ((1.0f / R.s.pdf) * R.wSum) / (float)R.M : 0.0f;
     }
     if (st.useTemporal) {
-        const uint32_t prevIdx = prev_pixel(cam, pos3(pp));
+        uint32_t prow;
+        const uint32_t prevIdx = prev_pixel(cam, pos3(pp), prow);
         const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
         GIRes prev = fr.giPrev[prevIdx];
-        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99;
+        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99 && prow >= fr.histBegin && prow < fr.histEnd;
         const f3 plo = lo3(prev.s);
         if (valid && prev.M > 0u && dot(plo, plo) > 0.0f) {
             GIRes Tm = R;

@@ -171,17 +171,50 @@ public:
     vec3& GetPosition() { return m_Position; }
     uint32_t GetViewportWidth() const { return m_W; }
     uint32_t GetViewportHeight() const { return m_H; }
+    // Camera::OnUpdate (Camera.cpp:18-94) with the right mouse button held; Walnut::Input is replaced by its values: `keys` = the
+    // pressed keys out of "WSADQE", `mouseDelta` = cursor movement in pixels.  Recalculates the view and leaves the
+    // previous-frame matrices alone (MainLayer::Render sets them after the frame, WalnutApp.cpp:908-909 == CommitFrame()).
+    bool OnUpdate(float ts, const char* keys, vec2 mouseDelta) {
+        const vec2 delta{mouseDelta.x * 0.002f, mouseDelta.y * 0.002f};
+        auto has = [keys](char k) { for (const char* p = keys; p && *p; ++p) if (*p == k) return true; return false; };
+        bool moved = false;
+        const vec3 up{0, 1, 0}, f = m_Forward, right = Cross(f, up);
+        const float speed = 5.0f;
+        auto add = [&](vec3 d, float sgn) { m_Position = vec3{m_Position.x + sgn * (d.x * speed * ts), m_Position.y + sgn * (d.y * speed * ts), m_Position.z + sgn * (d.z * speed * ts)}; moved = true; };
+        if (has('W')) add(f, 1.0f); else if (has('S')) add(f, -1.0f);
+        if (has('A')) add(right, -1.0f); else if (has('D')) add(right, 1.0f);
+        if (has('Q')) add(up, -1.0f); else if (has('E')) add(up, 1.0f);
+        if (delta.x != 0.0f || delta.y != 0.0f) {
+            const float pitch = delta.y * 0.3f, yaw = delta.x * 0.3f;
+            float q[4]; QuatMul(AngleAxis(-pitch, right).q, AngleAxis(-yaw, up).q, q);
+            const float n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            for (float& c : q) c /= n;
+            const vec3 qv{q[1], q[2], q[3]}, uv = Cross(qv, f), uuv = Cross(qv, uv);
+            m_Forward = vec3{f.x + (uv.x * q[0] + uuv.x) * 2.0f, f.y + (uv.y * q[0] + uuv.y) * 2.0f, f.z + (uv.z * q[0] + uuv.z) * 2.0f};
+            moved = true;
+        }
+        if (moved) RecalculateView();
+        return moved;
+    }
+    void CommitFrame() { m_PrevProjection = m_Projection; m_PrevView = m_View; }
 private:
-    void UpdateCameraView() {                          // Camera.cpp:108-134 (lookAt towards position + forward, up = +y)
+    struct Quat { float q[4]; };                       // (w, x, y, z)
+    static vec3 Cross(vec3 a, vec3 b) { return vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+    static Quat AngleAxis(float angle, vec3 axis) { const float h = angle * 0.5f, s = std::sin(h); return Quat{{std::cos(h), axis.x * s, axis.y * s, axis.z * s}}; }
+    static void QuatMul(const float* a, const float* b, float* o) {
+        o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3]; o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+        o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3]; o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+    }
+    void RecalculateView() {                           // Camera.cpp:127-134 (lookAt towards position + forward, up = +y)
         auto nrm = [](vec3 v) { float l = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); return vec3{v.x / l, v.y / l, v.z / l}; };
-        auto crs = [](vec3 a, vec3 b) { return vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
         auto dt = [](vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
-        const vec3 f = nrm(m_Forward), s = nrm(crs(f, vec3{0, 1, 0})), u = crs(s, f);
+        const vec3 f = nrm(m_Forward), s = nrm(Cross(f, vec3{0, 1, 0})), u = Cross(s, f);
         mat4 v;
         v.m[0] = s.x; v.m[4] = s.y; v.m[8] = s.z; v.m[1] = u.x; v.m[5] = u.y; v.m[9] = u.z; v.m[2] = -f.x; v.m[6] = -f.y; v.m[10] = -f.z;
         v.m[12] = -dt(s, m_Position); v.m[13] = -dt(u, m_Position); v.m[14] = dt(f, m_Position);
-        m_View = v; m_InverseView = Inverse(v); m_PrevProjection = m_Projection; m_PrevView = m_View;
+        m_View = v; m_InverseView = Inverse(v);
     }
+    void UpdateCameraView() { RecalculateView(); m_PrevProjection = m_Projection; m_PrevView = m_View; }   // Camera.cpp:108-116
     static mat4 Inverse(const mat4& a) {               // Gauss–Jordan in double on the column-major array
         double m[4][8];
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { m[r][c] = a.m[c * 4 + r]; m[r][4 + c] = (r == c) ? 1.0 : 0.0; }

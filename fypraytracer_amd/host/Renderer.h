@@ -53,8 +53,10 @@ public:
             if (m_HaveScene && sig == m_TopologySig &&
                 fyprt_update_vertices(m_Ctx, reinterpret_cast<const fyprt_vertex*>(scene.worldVertices.data()), (uint32_t)scene.worldVertices.size()) == FYPRT_OK) {
                 ++m_Refits;
+            } else if (UploadScene(scene)) {                 // remember the topology only of a scene the library really holds
+                m_TopologySig = sig; m_HaveScene = true; ++m_Uploads;
             } else {
-                UploadScene(scene); m_TopologySig = sig; m_HaveScene = true; ++m_Uploads;
+                m_HaveScene = false;
             }
             isSceneUpdated = false;
         }
@@ -104,7 +106,7 @@ private:
         for (const auto& t : scene.textures) { const uint64_t v[3] = {(uint64_t)(uintptr_t)t.pixels, t.width, t.height}; mix(v, sizeof v); }
         return h;
     }
-    template <class SceneT> void UploadScene(SceneT& scene) {                                 // SceneToGPU, Scene_GPU.cpp:6-81
+    template <class SceneT> bool UploadScene(SceneT& scene) {                                 // SceneToGPU, Scene_GPU.cpp:6-81
         fyprt_scene_desc d{};
         d.vertices = reinterpret_cast<const fyprt_vertex*>(scene.worldVertices.data()); d.vertex_count = (uint32_t)scene.worldVertices.size();
         d.triangles = scene.triangles.data(); d.triangle_count = (uint32_t)scene.triangles.size();
@@ -120,7 +122,7 @@ private:
         d.emissive_triangles = scene.emissiveTriangles.empty() ? nullptr : scene.emissiveTriangles.data();
         d.emissive_count = (uint32_t)scene.emissiveTriangles.size();
         d.light_trees = nullptr;                      // the library builds them (LightTree.cpp restated)
-        report(fyprt_upload_scene(m_Ctx, &d), "fyprt_upload_scene");
+        return !report(fyprt_upload_scene(m_Ctx, &d), "fyprt_upload_scene");
     }
     void Rezero(uint32_t w, uint32_t h) { m_Width = m_Height = 0; OnResize(w, h); }
     bool report(int rc, const char* what) {          // the reference prints and keeps going (Renderer.cu:29-47)

@@ -112,6 +112,32 @@ def inverse(m):
     return np.linalg.inv(m.astype(np.float64).T).T.astype(F)
 
 
+# glm quaternion helpers used by Camera::OnUpdate (gtc/quaternion: angleAxis, cross == Hamilton product, normalize, rotate)
+def _quat_angle_axis(angle, axis):
+    h = F(angle) * F(0.5)
+    s = F(math.sin(h))
+    return np.array([math.cos(h), axis[0] * s, axis[1] * s, axis[2] * s], dtype=F)      # (w, x, y, z)
+
+
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2, w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2], dtype=F)
+
+
+def _quat_normalize(q):
+    n = F(math.sqrt(float(np.dot(q, q))))
+    return (q / n).astype(F) if n > 0 else np.array([1, 0, 0, 0], dtype=F)
+
+
+def _quat_rotate(q, v):
+    qv = q[1:4]
+    uv = np.cross(qv, v).astype(F)
+    uuv = np.cross(qv, uv).astype(F)
+    return (v + ((uv * q[0]) + uuv) * F(2.0)).astype(F)
+
+
 class Camera:
     """Camera.h:9-83 / Camera.cpp.  `on_resize`, `set_position`, `set_direction` keep the
     reference's semantics, including the reset of the previous-frame matrices on an explicit
@@ -148,6 +174,40 @@ class Camera:
     def commit_frame(self):
         """MainLayer::Render tail (WalnutApp.cpp:908-909): prev := current."""
         self.prev_projection, self.prev_view = self.projection.copy(), self.view.copy()
+
+    def on_update(self, ts, keys="", mouse_delta=(0.0, 0.0)):
+        """Camera::OnUpdate (Camera.cpp:18-94) with the right mouse button held: `keys` is the set of pressed keys out of
+        "WSADQE", `mouse_delta` the cursor movement in pixels since the last call.  Moves / rotates the camera and
+        recalculates the view — the previous-frame matrices are NOT touched (only commit_frame / an explicit pose reset
+        do that), which is what makes ReSTIR's temporal reprojection land on a different pixel.  Returns `moved`."""
+        delta = (F(mouse_delta[0]) * F(0.002), F(mouse_delta[1]) * F(0.002))
+        moved = False
+        up = np.array([0, 1, 0], dtype=F)
+        fwd = self.forward.astype(F)
+        right = np.cross(fwd, up).astype(F)
+        speed, ts = F(5.0), F(ts)
+        keys = keys.upper()
+        if "W" in keys:
+            self.position = (self.position + fwd * speed * ts).astype(F); moved = True
+        elif "S" in keys:
+            self.position = (self.position - fwd * speed * ts).astype(F); moved = True
+        if "A" in keys:
+            self.position = (self.position - right * speed * ts).astype(F); moved = True
+        elif "D" in keys:
+            self.position = (self.position + right * speed * ts).astype(F); moved = True
+        if "Q" in keys:
+            self.position = (self.position - up * speed * ts).astype(F); moved = True
+        elif "E" in keys:
+            self.position = (self.position + up * speed * ts).astype(F); moved = True
+        if delta[0] != 0.0 or delta[1] != 0.0:
+            pitch, yaw = delta[1] * F(0.3), delta[0] * F(0.3)                    # GetRotationSpeed() = 0.3
+            q = _quat_normalize(_quat_mul(_quat_angle_axis(-pitch, right), _quat_angle_axis(-yaw, up)))
+            self.forward = _quat_rotate(q, fwd)
+            moved = True
+        if moved:                                                                # RecalculateView(): prev_* stay
+            self.view = look_at(self.position, self.position + self.forward, (0, 1, 0))
+            self.inverse_view = inverse(self.view)
+        return moved
 
     def ray_directions(self):
         """Camera::RecalculateRayDirections (Camera.cpp:136-153), numpy float32 — used only by

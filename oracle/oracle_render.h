@@ -29,6 +29,10 @@
 //       in the reference and then reads textures[] out of bounds; guarded as "no texture".
 //   R5  float -> int conversions that are UB for NaN / out-of-range (reprojection floor)
 //       are defined as NaN -> 0 and saturate.
+//   R7  Temporal history is used only where it exists and means something: (i) a tile-split render (rows [y0, y1) + halo)
+//       holds history for the rows it rendered LAST frame only — a reprojection landing outside them reads as "no history"
+//       (the whole frame when not split: no change to the reference); (ii) a DI history light index that is not in the
+//       current emissive list (scene replaced) reads as "no history" (the reference reads out of bounds).
 #pragma once
 #include "oracle_scene.h"
 
@@ -264,6 +268,7 @@ static inline float ComputeDirectEmitterPMF(const Scene& sc, const ShadingPoint&
 // =========================================================================== per-frame state + render
 struct Frame {
     uint32_t W = 0, H = 0, frameIndex = 1;
+    uint32_t histDI[2] = {0, 0}, histGI[2] = {0, 0};                             // R7 (i): rows holding DI / GI history
     std::vector<vec4> accum; std::vector<uint32_t> image;
     std::vector<Payload> payload; std::vector<float> depth; std::vector<vec2> normalPrev, normalCur;
     std::vector<DIReservoir> di, diPrev; std::vector<GIReservoir> gi, giPrev;
@@ -274,6 +279,7 @@ struct Frame {
         normalPrev.assign(n, vec2{0, 0}); normalCur.assign(n, vec2{0, 0});
         DIReservoir dz; std::memset(&dz, 0, sizeof dz); di.assign(n, dz); diPrev.assign(n, dz);
         GIReservoir gz; std::memset(&gz, 0, sizeof gz); gi.assign(n, gz); giPrev.assign(n, gz);
+        histDI[0] = histGI[0] = 0; histDI[1] = histGI[1] = h;
     }
 };
 
@@ -483,12 +489,13 @@ struct Renderer {
         return length(Lr);
     }
     // reprojection to the previous frame's pixel (Renderer.cu:1750-1763) + R5
-    uint32_t PrevPixel(vec3 worldPos) const {
+    uint32_t PrevPixel(vec3 worldPos, uint32_t& row) const {
         vec2 uvPrev = GetUVFromNDC(cam.prevProjection, cam.prevView, worldPos);
         vec2 viewport{(float)cam.width, (float)cam.height};
         vec2 sp = uvPrev * viewport;
         auto toInt = [](float f) -> int { if (!(f == f)) return 0; if (f >= 2147483520.0f) return 2147483647; if (f <= -2147483648.0f) return (-2147483647 - 1); return (int)f; };
         int px = iclamp(toInt(floorf(sp.x)), 0, (int)cam.width - 1), py = iclamp(toInt(floorf(sp.y)), 0, (int)cam.height - 1);
+        row = (uint32_t)py;
         return (uint32_t)py * cam.width + (uint32_t)px;
     }
     // spatial neighbour pick (Renderer.cu:1915-1922): unsigned wrap of x + int(...) included
@@ -523,10 +530,10 @@ struct Renderer {
         }
         R.weightEmissive = R.emissivePDF > 0.0f ? (1.0f / R.emissivePDF) * R.weightSum / (float)R.M : 0.0f;
         if (st.useTemporalReuse) {
-            uint32_t prevIdx = PrevPixel(pp.worldPosition);
+            uint32_t prow; uint32_t prevIdx = PrevPixel(pp.worldPosition, prow);
             vec3 prevNormal = DecodeOctahedral(fr.normalPrev[prevIdx]);
             DIReservoir prev = fr.diPrev[prevIdx];                               // R3: local copy
-            bool validHistory = (double)dot(prevNormal, pp.worldNormal) >= 0.99;
+            bool validHistory = (double)dot(prevNormal, pp.worldNormal) >= 0.99 && prow >= fr.histDI[0] && prow < fr.histDI[1] && prev.indexEmissive < nE;   // + R7
             DIReservoir T; DI_Reset(T);
             if (validHistory && prev.M > 0) {
                 uint8_t historyLimit = (uint8_t)st.temporalHistoryLimit;
@@ -643,10 +650,10 @@ struct Renderer {
             R.weightSample = R.sample.samplePDF > 0.0f ? (1.0f / R.sample.samplePDF) * R.weightSum / (float)R.M : 0.0f;
         }
         if (st.useTemporalReuse) {
-            uint32_t prevIdx = PrevPixel(pp.worldPosition);
+            uint32_t prow; uint32_t prevIdx = PrevPixel(pp.worldPosition, prow);
             vec3 prevNormal = DecodeOctahedral(fr.normalPrev[prevIdx]);
             GIReservoir prev = fr.giPrev[prevIdx];
-            bool validHistory = (double)dot(prevNormal, pp.worldNormal) >= 0.99;
+            bool validHistory = (double)dot(prevNormal, pp.worldNormal) >= 0.99 && prow >= fr.histGI[0] && prow < fr.histGI[1];   // + R7
             GIReservoir T = R;
             if (validHistory && GI_Valid(prev)) {
                 uint8_t historyLimit = (uint8_t)st.temporalHistoryLimit;
@@ -725,9 +732,14 @@ struct Renderer {
             #pragma omp parallel
             {
                 Counters local;
-                #pragma omp for schedule(dynamic, 4) nowait
-                for (int y = (int)ra; y < (int)rb; ++y)
-                    for (uint32_t x = 0; x < W; ++x) fn(x, (uint32_t)y, local);
+                // work items = 64-pixel row segments, dealt one at a time: 32 400 items at 1080p keep a few hundred host threads
+                // evenly busy (whole rows in chunks of 4 left half of a 256-thread host idle at the end of every pass)
+                const int segs = (int)((W + 63u) / 64u), items = (int)(rb - ra) * segs;
+                #pragma omp for schedule(dynamic, 1) nowait
+                for (int it = 0; it < items; ++it) {
+                    const uint32_t y = ra + (uint32_t)(it / segs), x0 = (uint32_t)(it % segs) * 64u, x1 = (x0 + 64u < W) ? x0 + 64u : W;
+                    for (uint32_t x = x0; x < x1; ++x) fn(x, y, local);
+                }
                 #pragma omp critical
                 { total.rays += local.rays; total.boxTests += local.boxTests; total.triTests += local.triTests; total.hits += local.hits; }
             }
@@ -751,6 +763,7 @@ struct Renderer {
                     Epilogue(i, (tech == RESTIR_DI) ? DI_Part2(x, y, c) : GI_Part2(x, y, c));
             });
             fr.normalPrev.swap(fr.normalCur);                                     // R2
+            if (tech == RESTIR_DI) { fr.histDI[0] = y0; fr.histDI[1] = y1; } else { fr.histGI[0] = y0; fr.histGI[1] = y1; }   // R7
         } else {
             rows(y0, y1, [&](uint32_t x, uint32_t y, Counters& c) {
                 vec4 col;

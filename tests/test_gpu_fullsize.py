@@ -132,3 +132,49 @@ def test_band_of_the_full_size_frame_against_the_oracle(hall, oracle_built):
     assert bits_equal(acc[y0:y1], orc.accum()[y0:y1]).all() and np.array_equal(img[y0:y1], orc.image()[y0:y1])
     assert orc.product_max_stack() <= 31
     ctx.close()
+
+
+def _band_against_oracle(hall, W, H, y0, y1, halo, st, frames=1):
+    from oraclelib import Oracle
+    cam = scenes.hall_camera(W, H)
+    ctx = capi.Context(0)
+    ctx.resize(W, H)
+    ctx.set_rows(y0, y1, halo)
+    ctx.upload_scene(hall)
+    ctx.set_camera(cam)
+    orc = Oracle(hall, W, H)
+    orc.set_camera(cam)
+    orc.use_product_bvh(ctx.export_bvh())
+    for f in range(frames):
+        st.rand_seed = f + 1
+        ctx.render(st)
+        orc.render(st, rows=(y0, y1), halo=halo)
+    img, acc = ctx.readback()
+    eq = bits_equal(acc[y0:y1], orc.accum()[y0:y1]).all(axis=-1)
+    assert eq.all(), f"{(~eq).sum()} of {eq.size} pixels differ"
+    assert np.array_equal(img[y0:y1], orc.image()[y0:y1])
+    assert orc.product_max_stack() <= 31
+    ctx.close()
+    return img, acc
+
+
+def test_config3_nee_band_of_the_full_size_frame_against_the_oracle(hall, oracle_built):
+    """BASELINE config 3 at full size: 64 rows of the 1920x1080 NEE + BRDF-MIS frame (2 bounces, 1 spp) of the 1M-triangle,
+    256-light hall against the oracle (same traversal over the exported tree, its own light trees): bit-exact.  Plus
+    determinism of the whole frame across two contexts."""
+    W, H = 1920, 1080
+    st = settings_for(capi.NEE, light_bounces=2, sample_count=1)
+    _band_against_oracle(hall, W, H, 500, 564, 0, st, frames=2)
+    cam = scenes.hall_camera(W, H)
+    a = _frames(hall, cam, W, H, capi.NEE, 2)
+    b = _frames(hall, cam, W, H, capi.NEE, 2)
+    assert _checksum(*a) == _checksum(*b)
+    assert np.isfinite(a[1]).all() and (a[0] >> 24 == 0xFF).all()
+
+
+def test_config5_gi_4k_band_against_the_oracle(hall, oracle_built):
+    """BASELINE config 5 at full size: 64 rows (+ 30-row halo, as one of 8 ranks renders them) of the 3840x2160 ReSTIR GI frame
+    against the oracle, two frames (the second one consumes the band's own temporal history): bit-exact."""
+    W, H = 3840, 2160
+    st = settings_for(capi.RESTIR_GI)
+    _band_against_oracle(hall, W, H, 1080, 1144, 30, st, frames=2)

@@ -106,3 +106,41 @@ def test_pipelined_frames_with_technique_switches(pipelined):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
     for a, b in zip(outs[0][2], outs[1][2]):
         assert a.tobytes() == b.tobytes()
+
+
+def test_light_sorted_tasks_with_pipelined_async_frames():
+    """Key 3 (counting sort of the shadow tasks) together with key 11 (two-stream pipelining): frame N+1's setup / scan / scatter
+    run beside frame N's trace kernel, which still reads its sorted index — the sort scratch alternates with the frame parity
+    like the task queues.  A long asynchronous run on a frame large enough for the kernels to overlap equals blocking frames."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 640, 360
+    cam = mk_cam(W, H)
+    outs = []
+    for use_async in (False, True):
+        ctx = capi.Context(0)
+        ctx.resize(W, H)
+        ctx.upload_scene(sc)
+        ctx.set_camera(cam)
+        ctx.set_tuning(3, 1)
+        ctx.set_tuning(11, 1)
+        st = settings_for(capi.RESTIR_DI)
+        for f in range(24):
+            st.rand_seed = f + 1
+            if use_async:
+                ctx.render_async(st)
+            else:
+                ctx.render(st)
+        ctx.synchronize()
+        outs.append(ctx.readback())
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
+
+
+def test_tuning_values_are_range_checked():
+    ctx = capi.Context(0)
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 0), (-1, 0)):
+        with pytest.raises(capi.FyprtError):
+            ctx.set_tuning(key, bad)
+    ctx.set_tuning(5, 64)
+    ctx.set_tuning(5, 24)
+    ctx.close()
