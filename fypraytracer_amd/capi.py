@@ -115,7 +115,7 @@ class FrameStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("kernel_ms_part", C.c_float * 4), ("rays", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("part_rays", C.c_uint64 * 4),
                 ("part_box_tests", C.c_uint64 * 4), ("part_tri_tests", C.c_uint64 * 4), ("part_hits", C.c_uint64 * 4),
-                ("launches", C.c_uint32)]
+                ("launches", C.c_uint32), ("node_visits", C.c_uint64), ("part_node_visits", C.c_uint64 * 4)]
 
 
 EXPORTED_SYMBOLS = [

@@ -11,7 +11,7 @@
 #include <hipcub/hipcub.hpp>
 #include "rt_lbvh.h"
 #include "rt_refit.h"
-#include "rt_wavefront.h"
+#include "rt_paths.h"
 
 using namespace rt;
 
@@ -76,6 +76,9 @@ struct fyprt_context {
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
     int tuning[13] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
+    // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
+    DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
+    int pathOcc = 0; size_t pathOccLds = 0;     // cached residency of k_trace_rays
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -141,8 +144,8 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     for (auto& row : c->ring) for (auto& e : row) (void)hipEventCreate(&e);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     (void)c->queueCounters.alloc(8);          // two queues (frame parity): tail, head, pad, pad each
-    (void)c->rayCounter.alloc(16);
-    (void)hipMemset(c->rayCounter.p, 0, 128);
+    (void)c->rayCounter.alloc(32);            // 4 launches x (rays, box tests, triangle tests, hits, node visits, 3 unused)
+    (void)hipMemset(c->rayCounter.p, 0, 256);
     *out = c;
     return FYPRT_OK;
 }
@@ -158,6 +161,8 @@ void fyprt_destroy(fyprt_context* c) {
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release(); c->ltLeafOfTri.release();
     c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
+    for (int k = 0; k < 2; ++k) { c->wfRays[k].release(); c->wfHits[k].release(); }
+    c->wfState.release(); c->wfPixels.release(); c->wfPixels2.release(); c->wfCounters.release();
     c->sortCounts.release(); c->sortOffset.release(); c->sortTotal.release(); c->sortIndex.release(); c->sortKeys.release(); c->sortHist.release();
     for (auto& row : c->ring) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) { if (c->evFront[k]) (void)hipEventDestroy(c->evFront[k]); if (c->evDone[k]) (void)hipEventDestroy(c->evDone[k]); }
@@ -530,6 +535,29 @@ int fyprt_set_camera(fyprt_context* c, const fyprt_camera_desc* cam) {
     return FYPRT_OK;
 }
 
+// (Re)sizes the buffers of the wavefront path engine: `entries` live paths at most, `raysPer` rays per path and step,
+// `stride` float4s of per-pixel state, `counters` list counters.  Grown on demand, kept between frames.
+static int ensure_paths(fyprt_context* c, size_t entries, uint32_t raysPer, uint32_t stride, size_t counters) {
+    const size_t npx = (size_t)c->W * c->H;
+    if (c->wfRays[0].n < entries * raysPer * 3 || c->wfHits[0].n < entries * raysPer) {
+        HIPCHK(c, sync_all(c));
+        for (int k = 0; k < 2; ++k) { HIPCHK(c, c->wfRays[k].alloc(entries * raysPer * 3)); HIPCHK(c, c->wfHits[k].alloc(entries * raysPer)); }
+    }
+    if (c->wfState.n < npx * stride) { HIPCHK(c, sync_all(c)); HIPCHK(c, c->wfState.alloc(npx * stride)); }
+    if (c->wfPixels.n < entries) { HIPCHK(c, sync_all(c)); HIPCHK(c, c->wfPixels.alloc(entries)); HIPCHK(c, c->wfPixels2.alloc(entries)); }
+    if (c->wfCounters.n < counters) { HIPCHK(c, sync_all(c)); HIPCHK(c, c->wfCounters.alloc(counters)); }
+    return FYPRT_OK;
+}
+
+typedef void (*shade_kernel_t)(DevScene, DevCamera, DevFrame, DevSettings, PathIO);
+static shade_kernel_t shade_kernel(int stage) {
+    switch (stage) {
+        case T_BRUTE: return k_shade<T_BRUTE>; case T_UNIFORM: return k_shade<T_UNIFORM>; case T_COSINE: return k_shade<T_COSINE>;
+        case T_GGX: return k_shade<T_GGX>; case T_BRDF: return k_shade<T_BRDF>; case T_LIGHT: return k_shade<T_LIGHT>;
+        case T_NEE: return k_shade<T_NEE>; case T_GI1: return k_shade<T_GI1>; default: return k_shade<T_GI2>;
+    }
+}
+
 static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) {
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context (device -1) cannot render");
     if (!c->haveScene || !c->haveCamera || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_render: resize, upload_scene and set_camera must precede render");
@@ -556,7 +584,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
     // node-loop quorum of the fused per-pixel kernels (key 7): 0 = auto — 16 for the light-tree kernels (their shadow rays: NEE 5.2 -> 4.95 ms),
     // none elsewhere (path and ReSTIR GI kernels: neutral or slightly negative)
-    c->dsc.nodeQuorum = c->tuning[7] > 0 ? (uint32_t)c->tuning[7] : ((tech == FYPRT_NEE || tech == FYPRT_LIGHT_SOURCE_SAMPLING) ? 16u : 0u);
+    c->dsc.nodeQuorum = (uint32_t)c->tuning[7];
     // traversal-stack budget (node_step's rule): never below the level count (the induction), never above the 31 the node
     // format records; by default a few entries above the level count, so the LDS stack is no larger than this tree needs
     // and more workgroups fit a CU (LDS is what limits residency: (budget + 1) KB per 256-thread workgroup)
@@ -576,7 +604,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
         HIPCHK(c, hipStreamWaitEvent(c->front, c->evDone[par], 0));                            // frame N-2 done: its queue is free
         if (!c->lastOverlapped) HIPCHK(c, hipStreamWaitEvent(c->front, c->evDone[par ^ 1], 0));   // frame N-1 ran on `stream` alone
     }
-    if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 128, c->stream));
+    if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 256, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51) — on `stream`, which owns it
     if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
@@ -593,14 +621,60 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     c->ev = c->ring[c->frameSerial % fyprt_context::kRing];
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
     int launches = 0;
+    // ---- wavefront path engine (rt_paths.h): primary kernel, then per step one shade launch + one persistent trace launch
+    struct StageRun { int stage; uint32_t steps, raysPer, stride; const uint32_t* pixelList; uint32_t* cnt; uint32_t* heads; uint32_t* part2List; uint32_t* part2Count; int counterPart; };
+    auto run_stage = [&](const StageRun& r) -> int {
+        const shade_kernel_t shade = shade_kernel(r.stage);
+        const dim3 shadeGrid((uint32_t)(c->numCUs * 8));
+        if (c->pathOccLds != ldsBytes) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_rays<false>, kBlock, ldsBytes) != hipSuccess || n <= 0) n = 4;
+            c->pathOcc = n; c->pathOccLds = ldsBytes;
+        }
+        const int perCU = c->tuning[2] > 0 ? c->tuning[2] : c->pathOcc;
+        DevScene tsc = c->dsc;
+        tsc.nodeQuorum = (uint32_t)c->tuning[6];                 // incoherent rays: leave the node loop once few lanes remain in it
+        tsc.rayCounter = c->countRays ? c->rayCounter.p + 8 * r.counterPart : nullptr;
+        for (uint32_t it = 0; it <= r.steps; ++it) {
+            PathIO io{};
+            io.pixelList = r.pixelList; io.raysIn = c->wfRays[it & 1u].p; io.hitsIn = c->wfHits[it & 1u].p; io.countIn = r.cnt + it;
+            io.raysOut = c->wfRays[(it + 1u) & 1u].p; io.countOut = r.cnt + it + 1; io.state = c->wfState.p; io.stateStride = r.stride;
+            io.iteration = it; io.raysPer = r.raysPer; io.part2List = r.part2List; io.part2Count = r.part2Count;
+            hipLaunchKernelGGL(shade, shadeGrid, block, 0, c->stream, c->dsc, c->dcam, fr, st, io);
+            if (it == r.steps) break;                                // the last step only consumes: every path has emitted all its rays
+            TraceQueue q{};
+            q.rays = io.raysOut; q.hits = c->wfHits[(it + 1u) & 1u].p; q.count = io.countOut; q.raysPer = r.raysPer; q.head = r.heads + it + 1;
+            q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24);
+            q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
+            if (c->countRays) hipLaunchKernelGGL(k_trace_rays<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
+            else hipLaunchKernelGGL(k_trace_rays<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
+            if (r.steps > 8u && (it & 3u) == 3u) {                   // long sample x bounce products: stop once no path is alive any more
+                uint32_t alive = 0;
+                HIPCHK(c, hipMemcpyAsync(&alive, io.countOut, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (alive == 0u) break;
+            }
+        }
+        return c->hip(hipGetLastError(), "path stage launch");
+    };
     switch (tech) {
-        case FYPRT_BRUTE_FORCE: hipLaunchKernelGGL(k_path<T_BRUTE>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_UNIFORM_SAMPLING: hipLaunchKernelGGL(k_path<T_UNIFORM>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_COSINE_WEIGHTED_SAMPLING: hipLaunchKernelGGL(k_path<T_COSINE>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_GGX_SAMPLING: hipLaunchKernelGGL(k_path<T_GGX>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_BRDF_SAMPLING: hipLaunchKernelGGL(k_path<T_BRDF>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_LIGHT_SOURCE_SAMPLING: hipLaunchKernelGGL(k_light_source, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
-        case FYPRT_NEE: hipLaunchKernelGGL(k_nee, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st); launches = 1; break;
+        case FYPRT_BRUTE_FORCE: case FYPRT_UNIFORM_SAMPLING: case FYPRT_COSINE_WEIGHTED_SAMPLING: case FYPRT_GGX_SAMPLING: case FYPRT_BRDF_SAMPLING:
+        case FYPRT_LIGHT_SOURCE_SAMPLING: case FYPRT_NEE: {
+            // rays a pixel emits one after the other = trace passes of the frame
+            const uint32_t nSamples = (tech == FYPRT_BRUTE_FORCE) ? 1u : st.sampleCount;
+            const uint32_t steps = (tech == FYPRT_LIGHT_SOURCE_SAMPLING) ? nSamples : nSamples * st.maxBounces;
+            const uint32_t raysPer = (tech == FYPRT_NEE && st.maxBounces != 1u) ? 2u : 1u;
+            const size_t entries = (size_t)(c->rowEnd - c->rowBegin) * c->W, L = (size_t)steps + 2;
+            { const int rc = ensure_paths(c, entries, raysPer, 3, 2 * L); if (rc != FYPRT_OK) return rc; }
+            HIPCHK(c, hipMemsetAsync(c->wfCounters.p, 0, 2 * L * sizeof(uint32_t), c->stream));
+            c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // coherent primary rays
+            if (c->countRays) hipLaunchKernelGGL(k_primary<true>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
+            else hipLaunchKernelGGL(k_primary<false>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
+            StageRun r{tech, steps, raysPer, 3u, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, nullptr, nullptr, 0};
+            { const int rc = run_stage(r); if (rc != FYPRT_OK) return rc; }
+            launches = 1;
+            break;
+        }
         case FYPRT_RESTIR_DI: case FYPRT_RESTIR_GI: {
             const uint32_t p1b = (c->rowBegin > c->halo) ? c->rowBegin - c->halo : 0u;
             const uint32_t p1e = (c->rowEnd + c->halo < c->H) ? c->rowEnd + c->halo : c->H;
@@ -612,11 +686,30 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             const bool extra = c->halo > 0 && c->rowBegin < c->halo && p1e < c->H;
             const uint32_t extraRow = extra ? c->H - 1u : 0xFFFFFFFFu;
             const dim3 g1 = gridFor(p1b, extra ? p1e + 16u : p1e);
-            if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part1, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
-            else hipLaunchKernelGGL(k_gi_part1, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
-            if (tech == FYPRT_RESTIR_DI) c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
+            if (tech == FYPRT_RESTIR_GI) {
+                // Part 1 = primary kernel + bounce-loop steps (they build the Part-2 list as paths complete); Part 2 = neighbour-loop steps
+                const size_t p1px = ((size_t)(p1e - p1b) + (extra ? 1u : 0u)) * c->W;
+                const uint32_t steps1 = st.maxBounces, steps2 = st.useSpatial ? st.numNeighbors : 0u;
+                const size_t L1 = (size_t)steps1 + 2, L2 = (size_t)steps2 + 2;
+                { const int rc = ensure_paths(c, p1px, 1, 6, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
+                uint32_t* cnt1 = c->wfCounters.p; uint32_t* cnt2 = cnt1 + 2 * L1;      // cnt2[0] = length of the Part-2 list
+                HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
+                if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
+                else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
+                StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0};
+                { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
+                if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+                StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1};
+                { const int rc = run_stage(r2); if (rc != FYPRT_OK) return rc; }
+                launches = 2;
+                c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;
+                break;
+            }
+            if (c->countRays) hipLaunchKernelGGL(k_di_part1<true>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+            else hipLaunchKernelGGL(k_di_part1<false>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+            c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
             if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
-            if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 4;      // per-launch counters
+            if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;      // per-launch counters
             launches = 2;
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
                 ShadowQueue q{};
@@ -637,23 +730,23 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evFront[par], 0));
                     if (timed) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));      // start of the trace kernel on its own stream
                 }
-                if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;
+                if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 16;
                 int perCU = c->tuning[2];
                 if (perCU <= 0) {          // as many workgroups as registers + LDS let a CU hold (asked from the runtime once per stack size)
                     if (c->traceOccLds != ldsBytes) {
                         int n = 0;
-                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_di_part2_trace, kBlock, ldsBytes) != hipSuccess || n <= 0) n = 4;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_di_part2_trace<false>, kBlock, ldsBytes) != hipSuccess || n <= 0) n = 4;
                         c->traceOcc = n; c->traceOccLds = ldsBytes;
                     }
                     perCU = c->traceOcc;
                 }
-                hipLaunchKernelGGL(k_di_part2_trace, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, c->dsc, fr, q);
+                if (c->countRays) hipLaunchKernelGGL(k_di_part2_trace<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, c->dsc, fr, q);
+                else hipLaunchKernelGGL(k_di_part2_trace<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, c->dsc, fr, q);
                 launches = 3;
             }
-            else if (tech == FYPRT_RESTIR_DI) hipLaunchKernelGGL(k_di_part2, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
-            else hipLaunchKernelGGL(k_gi_part2, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
-            if (tech == FYPRT_RESTIR_DI) { c->dprevFlip = !c->dprevFlip; c->histDI[0] = c->rowBegin; c->histDI[1] = c->rowEnd; }
-            else { c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd; }
+            else if (c->countRays) hipLaunchKernelGGL(k_di_part2<true>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
+            else hipLaunchKernelGGL(k_di_part2<false>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
+            c->dprevFlip = !c->dprevFlip; c->histDI[0] = c->rowBegin; c->histDI[1] = c->rowEnd;
             break;
         }
     }
@@ -685,10 +778,11 @@ int fyprt_render(fyprt_context* c, const fyprt_settings* s, fyprt_frame_stats* s
         }
         stats->kernel_ms = total;
         if (c->countRays) {
-            unsigned long long r[16] = {0}; (void)hipMemcpy(r, c->rayCounter.p, 128, hipMemcpyDeviceToHost);
+            unsigned long long r[32] = {0}; (void)hipMemcpy(r, c->rayCounter.p, 256, hipMemcpyDeviceToHost);
             for (int k = 0; k < 4; ++k) {
-                stats->part_rays[k] = r[4 * k + 0]; stats->part_box_tests[k] = r[4 * k + 1]; stats->part_tri_tests[k] = r[4 * k + 2]; stats->part_hits[k] = r[4 * k + 3];
-                stats->rays += r[4 * k + 0]; stats->box_tests += r[4 * k + 1]; stats->tri_tests += r[4 * k + 2]; stats->hits += r[4 * k + 3];
+                stats->part_rays[k] = r[8 * k + 0]; stats->part_box_tests[k] = r[8 * k + 1]; stats->part_tri_tests[k] = r[8 * k + 2]; stats->part_hits[k] = r[8 * k + 3];
+                stats->part_node_visits[k] = r[8 * k + 4];
+                stats->rays += r[8 * k + 0]; stats->box_tests += r[8 * k + 1]; stats->tri_tests += r[8 * k + 2]; stats->hits += r[8 * k + 3]; stats->node_visits += r[8 * k + 4];
             }
         }
     }

@@ -26,7 +26,7 @@ struct DevScene {
     const uint32_t* emissive; uint32_t emissiveCount; const float4* lightRecs;
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
     const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot; const uint32_t* ltLeafOfTri;
-    unsigned long long* rayCounter;   // nullptr = counting off; else [0] rays [1] box tests [2] triangle tests [3] hits
+    unsigned long long* rayCounter;   // instrumented kernel variants (template COUNT) only: [0] rays [1] box tests [2] triangle tests [3] hits [4] node visits
     int32_t stackBudget;              // pending-entry budget of node_step's stack rule (kStackBudget; tests lower it to exercise resume entries)
     uint32_t nodeQuorum;              // leave the inner-node loop when fewer lanes than this are still in it (0 = never)
 };
@@ -102,6 +102,8 @@ struct Stack {
 // with a 5-comparator network (ties keep slot order), the nearest is visited next and the others are pushed far-to-near.
 // Boxes are culled against `cut` (closest hit so far * 1.000001, or the light / visibility distance).
 typedef float v2f __attribute__((ext_vector_type(2)));
+// (a per-ray -(o/d) would make a node's B = (origin - o)/d one fma instead of sub + mul, but costs three more registers per lane: the
+// persistent trace kernels then lose a resident workgroup per CU, which is worth more than the 3 instructions — measured by register count)
 struct RayPk { float ox, oy, oz, ix, iy, iz; };
 RT_DEV RayPk make_raypk(f3 o, float ix, float iy, float iz) { RayPk r; r.ox = o.x; r.oy = o.y; r.oz = o.z; r.ix = ix; r.iy = iy; r.iz = iz; return r; }
 RT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); }
@@ -126,14 +128,17 @@ RT_DEV void order_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
 constexpr int32_t kResumeBase = 0x40000000;     // references >= this: resume entry, (ref - base) = node << 4 | slot mask
 constexpr int kStackBudget = kStackDepth - 1;   // one entry is the exit sentinel
 // returns the next reference to visit (a child, or the popped stack top when no child is hit)
-RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, bool counting) {
+// COUNT: instrumented variant (child-box tests and node visits per ray; fyprt_set_ray_counting) — the production kernels are
+// instantiated without it and carry neither the counters nor their instructions.
+template <bool COUNT>
+RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, uint32_t& nNode) {
     const bool resumed = cur >= kResumeBase;
     const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
     const float4* n = nodes + (size_t)node * 4;
     const float4 q0 = n[0], q1 = n[1], q2 = n[2];
     const float2 q3 = *reinterpret_cast<const float2*>(n + 3);
     const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u, levels = ex >> 27;
-    if (counting) nBox += (uint32_t)__popc((resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u));
+    if (COUNT) { nBox += (uint32_t)__popc((resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u)); nNode += 1u; }
     const float Ax = __int_as_float((int)((ex & 0xFFu) << 23)) * r.ix, Ay = __int_as_float((int)(((ex >> 8) & 0xFFu) << 23)) * r.iy,
                 Az = __int_as_float((int)(((ex >> 16) & 0xFFu) << 23)) * r.iz;
     const float Bx = (q0.x - r.ox) * r.ix, By = (q0.y - r.oy) * r.iy, Bz = (q0.z - r.oz) * r.iz;
@@ -167,9 +172,17 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     int32_t r0 = __float_as_int(q1.x), r1 = __float_as_int(q1.y), r2 = __float_as_int(q1.z), r3 = __float_as_int(q1.w);
     order_pair(k0, r0, k1, r1); order_pair(k2, r2, k3, r3); order_pair(k0, r0, k2, r2); order_pair(k1, r1, k3, r3); order_pair(k1, r1, k2, r2);
     if ((st.top - 1) + 2 + (int)levels <= budget) {
+        // unconditional stores, conditional advance: three ds_write_b32 without a branch each (entries top .. top + 2 exist: the
+        // rule above leaves room for them; a slot written for a child that was not hit is simply overwritten by the next push)
+#ifdef RT_COND_PUSH
         if (k3 < kMissKey) st.push(r3);
         if (k2 < kMissKey) st.push(r2);
         if (k1 < kMissKey) st.push(r1);
+#else
+        st.lds[st.top * kBlock] = r3; st.top += (k3 < kMissKey) ? 1 : 0;
+        st.lds[st.top * kBlock] = r2; st.top += (k2 < kMissKey) ? 1 : 0;
+        st.lds[st.top * kBlock] = r1; st.top += (k1 < kMissKey) ? 1 : 0;
+#endif
     } else if (k1 < kMissKey) {                                      // two or more hits and no room to push them one by one
         const uint32_t hit = (s0 < kMissKey ? 1u : 0u) | (s1 < kMissKey ? 2u : 0u) | (s2 < kMissKey ? 4u : 0u) | (s3 < kMissKey ? 8u : 0u);
         const uint32_t nearest = (s0 == k0) ? 1u : (s1 == k0) ? 2u : (s2 == k0) ? 4u : 8u;   // the sort keeps slot order on ties
@@ -186,22 +199,55 @@ RT_DEV bool ray_not_finite(f3 o, f3 d) {
 }
 RT_DEV float safe_inv(float d) { return 1.0f / ((__builtin_fabsf(d) < 1e-30f) ? __builtin_copysignf(1e-30f, d) : d); }
 
-// Closest hit over the two-level BVH.  Ordered traversal (near child first, far child pushed),
-// boxes culled against closest * 1.000001f; the ray / triangle test is Möller–Trumbore with
-// exactly the reference's operation order (Renderer.cu:513-537) on (v0, e1 = v1-v0, e2 = v2-v0),
-// accepting t > 1e-4 && t < closest, no back-face culling.
+// Möller–Trumbore with exactly the reference's operation order (Renderer.cu:513-537) on a leaf record (v0, e1 = v1-v0, e2 = v2-v0):
+// true and (t, u, v) if the ray passes through the triangle at t > 1e-4 (the caller compares t with its own interval), no culling.
+RT_DEV bool tri_test(const float4* tp, f3 o, f3 d, float& t, float& u, float& v, uint32_t& id) {
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    id = (uint32_t)__float_as_int(c.y);
+    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+    const f3 hh = cross(d, e2);
+    const float det = dot(e1, hh), f = 1.0f / det;
+    const f3 s = o - v0;
+    u = f * dot(s, hh);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(s, e1);
+    v = f * dot(d, q);
+    if (v < 0.0f || (u + v) > 1.0f) return false;
+    t = f * dot(e2, q);
+    return t > 0.0001f;
+}
+// the same test against an ORIGINAL triangle (triPos record): the light triangle of a shadow ray; -1 if it is not hit
+RT_DEV float light_tri_distance(const DevScene& sc, uint32_t tri, f3 o, f3 d) {
+    const float4* p = sc.triPos + (size_t)tri * 3;
+    const float4 a = p[0], b = p[1], c = p[2];
+    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z) - v0, e2 = mk3(c.x, c.y, c.z) - v0;
+    const f3 hh = cross(d, e2);
+    const float det = dot(e1, hh), f = 1.0f / det;
+    const f3 s = o - v0;
+    const float u = f * dot(s, hh);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const f3 q = cross(s, e1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || (u + v) > 1.0f) return -1.0f;
+    const float t = f * dot(e2, q);
+    return (t > 0.0001f) ? t : -1.0f;
+}
+
+// Closest hit over the acceleration structure (ONE tree: the reference's TLAS and per-mesh BLAS trees are merged at build).
+// Ordered traversal (nearest hit child first, the others pushed far-to-near), boxes culled against closest * 1.000001f; a
+// triangle is accepted when 1e-4 < t < closest, no back-face culling.
+template <bool COUNT>
 RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
     Hit h; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.tri = -1;
-    const bool counting = sc.rayCounter != nullptr;        // wave-uniform (kernel argument)
-    uint32_t nBox = 0, nTri = 0;
-    if (sc.triCount == 0 || ray_not_finite(o, d)) { if (counting) atomicAdd(sc.rayCounter, 1ull); return h; }
+    uint32_t nBox = 0, nTri = 0, nNode = 0;
+    if (sc.triCount == 0 || ray_not_finite(o, d)) { if (COUNT) atomicAdd(sc.rayCounter, 1ull); return h; }
     const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     float closestInfl = h.t * 1.000001f;
     Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
     int32_t cur = sc.rootRef;
     while (true) {
         while (cur >= 0) {
-            cur = node_step(sc.nodes, sc.stackBudget, cur, pk, closestInfl, st, nBox, counting);
+            cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, closestInfl, st, nBox, nNode);
             // lanes that reached a leaf wait outside this loop; once only a few lanes are still walking inner nodes,
             // stop and let everybody test their leaves (keeps SIMD lanes busy; pure scheduling, results unchanged)
             if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
@@ -210,26 +256,16 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
         if (cur == kExit) break;
         const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
         for (uint32_t k = 0; k < cnt; ++k) {
-            const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
-            const float4 a = tp[0], b = tp[1], c = tp[2];
-            if (counting) nTri += 1;
-            const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
-            const f3 hh = cross(d, e2);
-            const float det = dot(e1, hh), f = 1.0f / det;
-            const f3 s = o - v0;
-            const float u = f * dot(s, hh);
-            if (u < 0.0f || u > 1.0f) continue;
-            const f3 q = cross(s, e1);
-            const float v = f * dot(d, q);
-            if (v < 0.0f || (u + v) > 1.0f) continue;
-            const float t = f * dot(e2, q);
-            if (t > 0.0001f && t < h.t) { h.t = t; h.u = u; h.v = v; h.tri = __float_as_int(c.y); closestInfl = t * 1.000001f; }
+            float t, u, v; uint32_t id;
+            if (COUNT) nTri += 1;
+            if (tri_test(sc.leafTris + (size_t)(first + k) * 3, o, d, t, u, v, id) && t < h.t) { h.t = t; h.u = u; h.v = v; h.tri = (int32_t)id; closestInfl = t * 1.000001f; }
         }
         cur = st.pop();
     }
-    if (counting) {     // SURVEY.md §8(d) instrumentation; same counts as the oracle's restatement (tests/test_gpu_counters.py)
+    if (COUNT) {     // SURVEY.md §8(d) instrumentation; same counts as the oracle's restatement (tests/test_gpu_counters.py)
         atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
         atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, (unsigned long long)(h.tri >= 0 ? 1 : 0));
+        atomicAdd(sc.rayCounter + 4, (unsigned long long)nNode);
     }
     return h;
 }
@@ -243,31 +279,17 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
 // triangle itself (edge rounding) fall back to the full closest-hit query.  Exact-t ties count as
 // "not closer" (the reference's own tie order is traversal-order dependent).
 struct ShadowHit { float hitDistance; int32_t objectIndex; };
+template <bool COUNT>
 RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri, int32_t* ldsBase) {
     ShadowHit r;
-    const bool counting = sc.rayCounter != nullptr;
-    float tL = -1.0f;
-    {
-        const float4* p = sc.triPos + (size_t)lightTri * 3;
-        const float4 a = p[0], b = p[1], c = p[2];
-        const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z) - v0, e2 = mk3(c.x, c.y, c.z) - v0;
-        const f3 hh = cross(d, e2);
-        const float det = dot(e1, hh), f = 1.0f / det;
-        const f3 s = o - v0;
-        const float u = f * dot(s, hh);
-        if (!(u < 0.0f || u > 1.0f)) {
-            const f3 q = cross(s, e1);
-            const float v = f * dot(d, q);
-            if (!(v < 0.0f || (u + v) > 1.0f)) { const float t = f * dot(e2, q); if (t > 0.0001f) tL = t; }
-        }
-    }
+    const float tL = light_tri_distance(sc, lightTri, o, d);
     if (!(tL > 0.0f)) {                               // light not hit by its own shadow ray: exact fallback
-        if (counting) atomicAdd(sc.rayCounter + 2, 1ull);
-        const Hit h = trace_closest(sc, o, d, ldsBase);
+        if (COUNT) atomicAdd(sc.rayCounter + 2, 1ull);
+        const Hit h = trace_closest<COUNT>(sc, o, d, ldsBase);
         r.hitDistance = (h.tri < 0) ? -1.0f : h.t; r.objectIndex = h.tri;
         return r;
     }
-    uint32_t nBox = 0, nTri = 1;
+    uint32_t nBox = 0, nTri = 1, nNode = 0;
     const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     const float cut = tL * 1.000001f;
     Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
@@ -276,7 +298,7 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
     bool occluded = false;
     while (!occluded) {
         while (cur >= 0) {
-            cur = node_step(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, counting);
+            cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode);
             if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
         }
         if (cur >= 0) continue;
@@ -284,79 +306,19 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
         const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
         for (uint32_t k = 0; k < cnt; ++k) {
             const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
-            const float4 a = tp[0], b = tp[1], c = tp[2];
-            const uint32_t id = (uint32_t)__float_as_int(c.y);
-            if (id == lightTri) continue;
-            if (counting) nTri += 1;
-            const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
-            const f3 hh = cross(d, e2);
-            const float det = dot(e1, hh), f = 1.0f / det;
-            const f3 s = o - v0;
-            const float u = f * dot(s, hh);
-            if (u < 0.0f || u > 1.0f) continue;
-            const f3 q = cross(s, e1);
-            const float v = f * dot(d, q);
-            if (v < 0.0f || (u + v) > 1.0f) continue;
-            const float t = f * dot(e2, q);
-            if (t > 0.0001f && t < tL) { r.hitDistance = t; r.objectIndex = (int32_t)id; occluded = true; break; }
+            if ((uint32_t)__float_as_int(tp[2].y) == lightTri) continue;
+            float t, u, v; uint32_t id;
+            if (COUNT) nTri += 1;
+            if (tri_test(tp, o, d, t, u, v, id) && t < tL) { r.hitDistance = t; r.objectIndex = (int32_t)id; occluded = true; break; }
         }
         cur = st.pop();
     }
-    if (counting) {
+    if (COUNT) {
         atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
         atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, 1ull);
+        atomicAdd(sc.rayCounter + 4, (unsigned long long)nNode);
     }
     return r;
-}
-
-// Visibility query of ReSTIR GI Part 2 (R.cu:2356-2366): the reference traces a full closest-hit ray and accepts the
-// neighbour's sample iff |t_closest - dist| <= tol.  Equivalent without finding the closest hit: the interval is cut at
-// dist + tol, any triangle hit closer than dist - tol decides "not visible" at once, and the sample is visible iff some
-// triangle is hit inside [dist - tol, dist + tol].
-RT_DEV bool trace_visible(const DevScene& sc, f3 o, f3 d, float dist, float tol, int32_t* ldsBase) {
-    const bool counting = sc.rayCounter != nullptr;
-    uint32_t nBox = 0, nTri = 0;
-    bool found = false, blocked = false;
-    if (sc.triCount != 0 && !ray_not_finite(o, d)) {
-        const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-        const float tLo = dist - tol, tHi = dist + tol, cut = tHi * 1.000001f;
-        Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
-        int32_t cur = sc.rootRef;
-        while (!blocked) {
-            while (cur >= 0) {
-                cur = node_step(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, counting);
-                if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
-            }
-            if (cur >= 0) continue;
-            if (cur == kExit) break;
-            const uint32_t code = (uint32_t)~cur, first = code >> 2, cnt = (code & 3u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4* tp = sc.leafTris + (size_t)(first + k) * 3;
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                if (counting) nTri += 1;
-                const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
-                const f3 hh = cross(d, e2);
-                const float det = dot(e1, hh), f = 1.0f / det;
-                const f3 s = o - v0;
-                const float u = f * dot(s, hh);
-                if (u < 0.0f || u > 1.0f) continue;
-                const f3 q = cross(s, e1);
-                const float v = f * dot(d, q);
-                if (v < 0.0f || (u + v) > 1.0f) continue;
-                const float t = f * dot(e2, q);
-                if (t > 0.0001f) {
-                    if (t < tLo) { blocked = true; break; }
-                    if (t <= tHi) found = true;
-                }
-            }
-            cur = st.pop();
-        }
-    }
-    if (counting) {
-        atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
-        atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, (unsigned long long)((found && !blocked) ? 1 : 0));
-    }
-    return found && !blocked;
 }
 
 // Miss (Renderer.cu:2423-2429; worldPosition / objectIndex zero-filled / -1: DESIGN.md §5 R1)
@@ -375,8 +337,9 @@ RT_DEV Payload make_hit(const DevScene& sc, f3 o, f3 d, const Hit& h) {
     p.v = (s1.w * w + s3.x * h.u) + s3.z * h.v;      // uv0.y, uv1.y, uv2.y
     return p;
 }
+template <bool COUNT>
 RT_DEV Payload trace_ray(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
-    const Hit h = trace_closest(sc, o, d, ldsBase);
+    const Hit h = trace_closest<COUNT>(sc, o, d, ldsBase);
     return (h.tri < 0) ? make_miss() : make_hit(sc, o, d, h);
 }
 

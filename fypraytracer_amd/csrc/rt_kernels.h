@@ -1,26 +1,11 @@
-// Per-pixel techniques (the reference's nine sampling techniques) as gfx950 kernels.
-// Each kernel cites the reference function it computes; the arithmetic order is the
-// reference's (Renderer.cu:565-2387), the execution structure is ours: one wave covers an
-// 8x8 pixel tile (coherent primary rays), 4 waves per workgroup, traversal stack in LDS,
-// scene read through the quad streams of rt_device.h, accumulation / tonemap / pack fused.
+// Shading functions of the reference's nine sampling techniques + the ReSTIR DI kernels (gfx950).
+// Each function cites the reference code it computes; the arithmetic order is the reference's (Renderer.cu:565-2387), the
+// execution structure is ours: primary rays one wave per 8x8 pixel tile (coherent), 4 waves per workgroup, traversal stack in
+// LDS, scene read through the quad streams of rt_device.h, accumulation / tonemap / pack fused.  Techniques 0-6 and ReSTIR GI
+// run as wavefront stages (rt_paths.h); ReSTIR DI as Part 1 + setup + persistent trace (rt_wavefront.h).
 #pragma once
 #include "rt_device.h"
 
-// Register budgets of the fat one-thread-per-pixel kernels: the compiler's own allocation leaves the light-tree kernels at 2 waves
-// per SIMD (171-184 VGPRs); capping them at the budget of 4 waves (128 VGPRs, a few spills) is 1.45x faster (7.5 -> 5.2 ms for
-// config 3; 3, 5 and 6 waves measured too: 5.8 / 5.4 / 6.4 ms).
-#ifndef RT_NEE_WAVES
-#define RT_NEE_WAVES __attribute__((amdgpu_waves_per_eu(4, 8)))
-#endif
-// The path and ReSTIR GI kernels (95-155 and 114 VGPRs) likewise: capped at the budget of 7 waves (72 VGPRs) — which is also what
-// the 22 KB LDS stack lets a CU hold — 4K ReSTIR GI 15.8 -> 13.6 ms, cosine 4 spp 1.36 -> 1.18 ms, BRDF sampling on the 1M-triangle
-// scene 2.79 -> 2.08 ms (5 / 6 / 8 waves: 14.6 / 13.8 / 14.2 ms for GI).
-#ifndef RT_GI_WAVES
-#define RT_GI_WAVES __attribute__((amdgpu_waves_per_eu(7, 8)))
-#endif
-#ifndef RT_PATH_WAVES
-#define RT_PATH_WAVES __attribute__((amdgpu_waves_per_eu(7, 8)))
-#endif
 namespace rt {
 
 enum Tech { T_BRUTE = 0, T_UNIFORM = 1, T_COSINE = 2, T_GGX = 3, T_BRDF = 4, T_LIGHT = 5, T_NEE = 6, T_DI = 7, T_GI = 8 };
@@ -85,52 +70,6 @@ RT_DEV f3 sample_dir(f3 n, f3 V, const Mat& m, f3 albedo, float ggxRoughness, ui
     if (TECH == T_COSINE) { pdf = -1.0f; return sample_cosine(n, seed); }
     if (TECH == T_GGX) return sample_ggx(n, V, ggxRoughness, seed, pdf);
     return sample_brdf(n, V, albedo, m.metallic, m.roughness, seed, pdf);
-}
-
-template <int TECH>
-__global__ __launch_bounds__(kBlock) RT_PATH_WAVES void k_path(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
-    uint32_t x, y;
-    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
-    int32_t* stk = s_stack + threadIdx.x;
-    const uint32_t i = x + y * fr.W;
-    uint32_t seed = i * fr.frameIndex;
-    const f3 pd = ray_direction(cam, x, y);
-    const Payload pp = trace_ray(sc, cam.position, pd, stk);
-    if (pp.hitDistance < 0.0f) { epilogue(fr, i, rgb1(st.sky)); return; }
-    const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
-    if (length(emission(hm)) > 0.0f) { epilogue(fr, i, rgb1(emission(hm))); return; }
-    f3 radiance = splat3(0.0f);
-    const int nSamples = (TECH == T_BRUTE) ? 1 : (int)st.sampleCount;
-    const f3 palbedo = sample_albedo(sc, hm, pp.u, pp.v);
-    for (int s = 0; s < nSamples; ++s) {
-        if (TECH != T_BRUTE) seed += (uint32_t)((s + 1) * 27);
-        float pdf;
-        f3 dir = sample_dir<TECH>(nrm3(pp), -pd, hm, palbedo, hm.roughness, seed, pdf);
-        f3 brdf = eval_brdf(nrm3(pp), -pd, dir, palbedo, hm.metallic, hm.roughness);
-        float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
-        if (TECH == T_COSINE) pdf = pdf_cosine(cosT);
-        f3 T = splat3(1.0f) * ((brdf * cosT) / pdf);
-        f3 ro = pos3(pp) + nrm3(pp) * 1e-12f, rd = dir;
-        for (int b = 0; b < (int)st.maxBounces; ++b) {
-            seed += (uint32_t)(((TECH == T_BRUTE) ? 0 : s) + 31 * b);
-            const Payload hit = trace_ray(sc, ro, rd, stk);
-            if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; break; }
-            const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
-            const f3 em = emission(m);
-            if (length(em) > 0.0f) { radiance = radiance + T * em; break; }
-            const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
-            float bpdf;
-            const f3 bdir = sample_dir<TECH>(nrm3(hit), -rd, m, alb, hm.roughness /* primary roughness, Renderer.cu:1091-1092 */, seed, bpdf);
-            const f3 bbrdf = eval_brdf(nrm3(hit), -rd, bdir, alb, m.metallic, m.roughness);
-            const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
-            if (TECH == T_COSINE) bpdf = pdf_cosine(bcos);
-            T = T * ((bbrdf * bcos) / bpdf);
-            ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
-        }
-    }
-    if (TECH != T_BRUTE) radiance = radiance / (float)st.sampleCount;
-    epilogue(fr, i, rgb1(radiance));
 }
 
 // ============================================================ light tree (LightTree.cuh:91-117, LightTree.cu, ConeBounds.cuh:47-87)
@@ -212,120 +151,6 @@ RT_DEV float direct_emitter_pmf(const DevScene& sc, f3 spPos, uint32_t emitterTr
     return pmf;
 }
 
-// ============================================================ LIGHT_SOURCE_SAMPLING (Renderer.cu:1287-1408)
-__global__ __launch_bounds__(kBlock) RT_NEE_WAVES void k_light_source(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
-    uint32_t x, y;
-    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
-    int32_t* stk = s_stack + threadIdx.x;
-    const uint32_t i = x + y * fr.W;
-    uint32_t seed = i * fr.frameIndex;
-    const f3 pd = ray_direction(cam, x, y);
-    const Payload pp = trace_ray(sc, cam.position, pd, stk);
-    if (pp.hitDistance < 0.0f) { epilogue(fr, i, rgb1(st.sky)); return; }
-    const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
-    if (length(emission(hm)) > 0.0f) { epilogue(fr, i, rgb1(emission(hm))); return; }
-    f3 radiance = splat3(0.0f);
-    const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
-    for (int s = 0; s < (int)st.sampleCount; ++s) {
-        seed += (uint32_t)((s + 1) * 27);
-        const PickedLight pl = pick_light(sc, pos3(pp), seed);
-        const TriGeom g = load_tri(sc, pl.tri);
-        const f3 ep = tri_random_point(g, seed);
-        f3 dir = ep - pos3(pp);
-        const float dist = length(pos3(pp) - ep);
-        dir = dir / dist;
-        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
-        const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
-        const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
-        const float triAreaPDF = 1.0f / tri_area(g);
-        const float totalPDF = (pl.pmf * triAreaPDF) * (dist * dist);
-        const f3 T = splat3(1.0f) * (((brdf * cx) * cy) / totalPDF);
-        const ShadowHit hit = trace_shadow(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, pl.tri, stk);
-        if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; continue; }
-        if ((uint32_t)hit.objectIndex != pl.tri) continue;
-        const Mat lm = load_mat(sc, g.mat);
-        if (length(emission(lm)) > 0.0f) radiance = radiance + T * emission(lm);
-    }
-    radiance = radiance / (float)st.sampleCount;
-    epilogue(fr, i, rgb1(radiance));
-}
-
-// ============================================================ NEE (Renderer.cu:1411-1626)
-__global__ __launch_bounds__(kBlock) RT_NEE_WAVES void k_nee(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
-    uint32_t x, y;
-    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
-    int32_t* stk = s_stack + threadIdx.x;
-    const uint32_t i = x + y * fr.W;
-    uint32_t seed = i * fr.frameIndex;
-    const f3 pd = ray_direction(cam, x, y);
-    const Payload pp = trace_ray(sc, cam.position, pd, stk);
-    if (pp.hitDistance < 0.0f) { epilogue(fr, i, rgb1(st.sky)); return; }
-    {
-        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
-        if (length(emission(hm)) > 0.0f) { epilogue(fr, i, rgb1(emission(hm))); return; }
-    }
-    f3 radiance = splat3(0.0f);
-    const uint32_t maxBounces = st.maxBounces;
-    for (int s = 0; s < (int)st.sampleCount; ++s) {
-        seed += (uint32_t)((s + 1) * 31);
-        f3 T = splat3(1.0f), rd = pd;
-        Payload hit = pp;
-        float pdfBRDF = 1.0f, pdfDirect = 1.0f;
-        for (uint32_t bounce = 0; bounce < maxBounces; ++bounce) {
-            const Mat mat = load_mat(sc, tri_material(sc, hit.objectIndex));
-            const f3 albedo = sample_albedo(sc, mat, hit.u, hit.v);
-            const PickedLight pl = pick_light(sc, pos3(hit), seed);
-            const TriGeom g = load_tri(sc, pl.tri);
-            const f3 lp = tri_random_point(g, seed);
-            f3 ld = lp - pos3(hit);
-            const float dist = length(ld);
-            ld = ld / dist;
-            const ShadowHit sh = trace_shadow(sc, pos3(hit) + nrm3(hit) * 1e-12f, ld, pl.tri, stk);
-            if (sh.hitDistance > 0.0f && (uint32_t)sh.objectIndex == pl.tri) {
-                const f3 brdf = eval_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
-                const float cx = gmax(dot(ld, nrm3(hit)), 0.0f);
-                const float cy = gmax(dot(-ld, tri_normal(g)), 1e-12f);
-                const float triAreaPDF = 1.0f / tri_area(g);
-                const float lsa = (triAreaPDF * (dist * dist)) / cy;
-                pdfDirect = pl.pmf * lsa;
-                pdfBRDF = pdf_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
-                const f3 em = emission(load_mat(sc, g.mat));
-                if (maxBounces == 1) { radiance = radiance + (((T * brdf) * cx) * em) / pdfDirect; break; }
-                const float wD = pdfDirect / gmax(pdfBRDF + pdfDirect, 1e-12f);
-                radiance = radiance + ((((wD * T) * brdf) * cx) * em) / pdfDirect;
-            }
-            if (maxBounces == 1) break;
-            const f3 nd = sample_brdf(nrm3(hit), -rd, albedo, mat.metallic, mat.roughness, seed, pdfBRDF);
-            pdfBRDF = gmax(pdfBRDF, 1e-12f);
-            const f3 brdf = eval_brdf(nrm3(hit), -rd, nd, albedo, mat.metallic, mat.roughness);
-            const float cosT = dot(nd, nrm3(hit));
-            T = T * ((brdf * cosT) / pdfBRDF);
-            const f3 ro = pos3(hit) + nrm3(hit) * 1e-12f;
-            rd = nd;
-            hit = trace_ray(sc, ro, rd, stk);
-            if (hit.hitDistance < 0.0f) { radiance = radiance + T * st.sky; break; }
-            const Mat em = load_mat(sc, tri_material(sc, hit.objectIndex));
-            if (length(emission(em)) > 0.0f) {
-                const TriGeom eg = load_tri(sc, (uint32_t)hit.objectIndex);
-                const f3 lp2 = tri_random_point(eg, seed);
-                f3 ld2 = lp2 - pos3(hit);
-                const float dist2 = length(ld2);
-                ld2 = ld2 / dist2;
-                const float cy = gmax(dot(-ld2, tri_normal(eg)), 1e-12f);
-                const float triAreaPDF = 1.0f / tri_area(eg);
-                const float lsa = (triAreaPDF * (dist2 * dist2)) / cy;
-                pdfDirect = direct_emitter_pmf(sc, pos3(hit), (uint32_t)hit.objectIndex) * lsa;
-                const float wB = pdfBRDF / gmax(pdfBRDF + pdfDirect, 1e-12f);
-                radiance = radiance + (wB * T) * emission(em);
-                break;
-            }
-        }
-    }
-    epilogue(fr, i, rgb1(radiance / (float)st.sampleCount));
-}
-
 // ============================================================ ReSTIR DI (Renderer.cu:1628-2041)
 RT_DEV bool di_update(DIRes& r, uint32_t cand, float w, uint32_t count, float pdf, uint32_t& seed) {   // ReSTIR_DI_Reservoir.cu:3-36
     r.wSum += w; r.M += count;
@@ -388,6 +213,7 @@ RT_DEV uint32_t neighbor_index(const DevCamera& cam, uint32_t W, uint32_t x, uin
 
 // Part 1 rows: [p1Begin, p1End) (band + halo); finished pixels (sky / emitter) go through the
 // epilogue only inside the band proper so halo rows never touch accumulation.
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
@@ -397,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
     const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
     uint32_t seed = i * (fr.frameIndex + 1u + st.randSeed);
     const f3 pd = ray_direction(cam, x, y);
-    const Payload pp = trace_ray(sc, cam.position, pd, stk);
+    const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, stk);
     fr.payload[i] = pp;
     const f2 ncur = oct_encode(nrm3(pp));
     DIRes R = di_empty();
@@ -452,6 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
     if (inBand && fr.p1Mode == 0u) fr.image[i] = 0u;     // sentinel: ConvertToRGBA(vec4(0)) (Renderer.cu:2746-2750)
 }
 
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
@@ -496,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
     const float triAreaPDF = 1.0f / tri_area(g);
     const float sa = triAreaPDF * (dist * dist);
     const f3 T = ((brdf * cx) * cy) / sa;
-    const ShadowHit hit = trace_shadow(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, ti, stk);
+    const ShadowHit hit = trace_shadow<COUNT>(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, ti, stk);
     f3 radiance = splat3(0.0f);
     if ((uint32_t)hit.objectIndex == ti && hit.hitDistance >= 0.0f) {
         const Mat lm = load_mat(sc, g.mat);
@@ -521,133 +348,5 @@ RT_DEV void gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {     
     r.M = prev + o.M;
 }
 RT_DEV f3 lo3(const GISample& s) { return mk3(s.Lo[0], s.Lo[1], s.Lo[2]); }
-
-__global__ __launch_bounds__(kBlock) RT_GI_WAVES void k_gi_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
-    uint32_t x, y;
-    if (!p1_pixel_of_thread(fr, p1Begin, p1End, extraRow, x, y)) return;
-    int32_t* stk = s_stack + threadIdx.x;
-    const uint32_t i = x + y * fr.W;
-    const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
-    uint32_t seed = i * (fr.frameIndex + 1u + st.randSeed);
-    const f3 pd = ray_direction(cam, x, y);
-    const Payload pp = trace_ray(sc, cam.position, pd, stk);
-    fr.payload[i] = pp;
-    fr.normalCur[i] = oct_encode(nrm3(pp));
-    GIRes R; gi_reset(R);
-    bool finished = false; f3 finalColor = splat3(0.0f);
-    Mat hm;
-    if (pp.hitDistance < 0.0f) { finished = true; finalColor = st.sky; }
-    else {
-        hm = load_mat(sc, tri_material(sc, pp.objectIndex));
-        if (length(emission(hm)) > 0.0f) { finished = true; finalColor = emission(hm); }
-    }
-    if (finished) {
-        fr.gi[i] = R; fr.depth[i] = pp.hitDistance;
-        if (inBand) epilogue(fr, i, rgb1(finalColor));
-        return;
-    }
-    {
-        const uint32_t originalSeed = seed;
-        f3 T = splat3(1.0f), Lo = splat3(0.0f), samplePoint = splat3(0.0f), sampleNormal = splat3(0.0f);
-        const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
-        float pdf;
-        const f3 dir = sample_brdf(nrm3(pp), -pd, albedo, hm.metallic, hm.roughness, seed, pdf);
-        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
-        const float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
-        T = T * ((brdf * cosT) / pdf);
-        f3 ro = pos3(pp) + nrm3(pp) * 1e-12f, rd = dir;
-        for (int b = 0; b < (int)st.maxBounces; ++b) {
-            seed += (uint32_t)(31 * b);
-            const Payload hit = trace_ray(sc, ro, rd, stk);
-            if (b == 0) { samplePoint = pos3(hit); sampleNormal = nrm3(hit); }
-            if (hit.hitDistance < 0.0f) { Lo = Lo + T * st.sky; break; }
-            const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
-            const f3 em = emission(m);
-            if (length(em) > 0.0f) { Lo = Lo + T * em; break; }
-            const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
-            float bpdf;
-            const f3 bdir = sample_brdf(nrm3(hit), -rd, alb, m.metallic, m.roughness, seed, bpdf);
-            const f3 bbrdf = eval_brdf(nrm3(hit), -rd, bdir, alb, m.metallic, m.roughness);
-            const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
-            T = T * ((bbrdf * bcos) / bpdf);
-            ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
-        }
-        GISample s; s.seed = originalSeed;
-        s.vp[0] = pp.px; s.vp[1] = pp.py; s.vp[2] = pp.pz;
-        const f2 vn = oct_encode(nrm3(pp)); s.vn[0] = vn.x; s.vn[1] = vn.y;
-        s.sp[0] = samplePoint.x; s.sp[1] = samplePoint.y; s.sp[2] = samplePoint.z;
-        const f2 sn = oct_encode(sampleNormal); s.sn[0] = sn.x; s.sn[1] = sn.y;
-        s.Lo[0] = Lo.x; s.Lo[1] = Lo.y; s.Lo[2] = Lo.z; s.pdf = 0.0f;
-        const float len = length(Lo);
-        gi_update(R, s, len, 1u, len, seed);
-        R.W = R.s.pdf > 0.0f ? ((1.0f / R.s.pdf) * R.wSum) / (float)R.M : 0.0f;
-    }
-    if (st.useTemporal) {
-        uint32_t prow;
-        const uint32_t prevIdx = prev_pixel(cam, pos3(pp), prow);
-        const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
-        GIRes prev = fr.giPrev[prevIdx];
-        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99 && prow >= fr.histBegin && prow < fr.histEnd;
-        const f3 plo = lo3(prev.s);
-        if (valid && prev.M > 0u && dot(plo, plo) > 0.0f) {
-            GIRes Tm = R;
-            const uint32_t lim = st.historyLimit * R.M;
-            prev.M = (lim < prev.M) ? lim : prev.M;
-            const float pdf = length(plo);
-            gi_update(Tm, prev.s, (pdf * prev.W) * (float)prev.M, prev.M, pdf, seed);
-            Tm.W = Tm.s.pdf > 0.0f ? Tm.s.pdf / ((float)Tm.M * Tm.s.pdf) : 0.0f;
-            gi_reset(R);
-            gi_merge(R, Tm, Tm.s.pdf, seed);
-        }
-    }
-    fr.gi[i] = R;
-    if (inBand) fr.image[i] = 0u;
-}
-
-__global__ __launch_bounds__(kBlock) RT_GI_WAVES void k_gi_part2(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
-    uint32_t x, y;
-    if (!pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y)) return;
-    int32_t* stk = s_stack + threadIdx.x;
-    const uint32_t i = x + y * fr.W;
-    if (fr.image[i] != 0u) return;
-    GIRes R = fr.gi[i];
-    const Payload pp = fr.payload[i];
-    uint32_t seed = i * (fr.frameIndex + 213u + st.randSeed);
-    if (st.useSpatial) {
-        const float plen = length(lo3(R.s));
-        uint32_t Z = plen > 0.0f ? R.M : 0u;
-        for (uint32_t n = 0; n < st.numNeighbors; ++n) {
-            const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
-            const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
-            const GIRes N = fr.gi[ni];
-            const float nlen = length(lo3(N.s));
-            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906 || nlen == 0.0f) continue;
-            Z += N.M;
-            f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
-            const f3 sn = oct_decode(sne);
-            const f3 nvp = mk3(N.s.vp[0], N.s.vp[1], N.s.vp[2]), nsp = mk3(N.s.sp[0], N.s.sp[1], N.s.sp[2]);
-            const f3 rvp = mk3(R.s.vp[0], R.s.vp[1], R.s.vp[2]);
-            const f3 dQ = normalize(nvp - nsp);
-            const float cosQ = dot(sn, dQ);
-            const f3 dR = normalize(rvp - nsp);
-            const float cosR = dot(sn, dR);
-            const float jl = cosQ > 0.0f ? cosR / cosQ : 0.0f;
-            const float distQ = length(nvp - nsp), distR = length(rvp - nsp);
-            const float jr = distR > 0.0f ? (distQ * distQ) / (distR * distR) : 0.0f;
-            const float jac = jl * jr;
-            float pdf = jac > 0.0f ? nlen / jac : 0.0f;
-            const float tol = gmax(1e-4f, distR * 1e-3f);
-            if (!trace_visible(sc, nsp, dR, distR, tol, stk)) pdf = 0.0f;
-            gi_merge(R, N, pdf, seed);
-        }
-        R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;
-    }
-    const f3 radiance = lo3(R.s) * R.W;
-    fr.depth[i] = pp.hitDistance;
-    fr.giPrev[i] = R;
-    epilogue(fr, i, rgb1(radiance));
-}
 
 }  // namespace rt

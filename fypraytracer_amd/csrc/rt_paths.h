@@ -1,0 +1,528 @@
+// Wavefront path engine: techniques 0-6 (brute force, uniform, cosine, GGX, BRDF, light-source sampling, NEE + MIS) and
+// ReSTIR GI Part 1 / Part 2 as STAGES instead of one-thread-per-pixel megakernels:
+//
+//   k_primary / k_gi_primary   one thread per pixel, wave = 8x8 tile: primary ray (coherent, traversal stack in LDS), payload;
+//                              pixels that saw the sky or an emitter are finished on the spot, the others are appended to a list
+//   k_shade<TECH>, step k      one thread per LIVE path, no traversal state at all: consumes the results of the rays the path
+//                              emitted in step k-1 (rt_wavefront.h ray records), runs the technique's shading / sampling code up
+//                              to the next point where it needs a ray, emits that ray (or two: NEE's shadow + bounce ray) into
+//                              the next list — compacted with wave ballot + prefix popcount, an LDS prefix over the 4 waves and
+//                              ONE atomic per workgroup — or finishes the pixel (fused epilogue)
+//   k_trace_rays               persistent waves over the emitted rays (closest hit / shadow / visibility), rt_wavefront.h
+//
+// so that no kernel holds traversal state and shading state at once (the megakernels spilled 24-132 VGPRs each) and SIMD lanes
+// are re-packed after every bounce.  The reference's loops (R.cu:565-1284 sample x bounce, :1287-1408 light-source samples,
+// :1411-1626 NEE sample x bounce, :2043-2293 GI bounce loop, :2295-2387 GI neighbour loop) become state machines: the per-pixel
+// state between two steps lives in a small record (`PathIO::state`), everything that is a pure function of the primary hit is
+// recomputed.  The arithmetic — every expression, its operation order, the order of the random numbers drawn from the per-pixel
+// seed, the order in which contributions are added to the radiance — is the megakernels' (and the reference's), so every output
+// bit is unchanged; tests/test_gpu_parity.py compares all of it with the oracle.
+#pragma once
+#include "rt_wavefront.h"
+
+namespace rt {
+
+enum { T_GI1 = 9, T_GI2 = 10 };          // stage ids beyond the SamplingTechniqueEnum values (Tech)
+
+struct PathIO {
+    const uint32_t* pixelList;           // step 0: the owners come from this list (written by the primary kernel / by GI Part 1)
+    const float4* raysIn; const float4* hitsIn; const uint32_t* countIn;     // rays emitted by the previous step, their results, number of ENTRIES
+    float4* raysOut; uint32_t* countOut;                                      // rays of the next step
+    float4* state; uint32_t stateStride;                                      // per-pixel path state, float4 units
+    uint32_t iteration, raysPer;                                              // rays per entry (2 for NEE with more than one bounce)
+    uint32_t* part2List; uint32_t* part2Count;                                // ReSTIR GI: pixels that continue into Part 2
+};
+
+struct RayRec { float4 q0, q1, q2; };
+RT_DEV RayRec ray_closest(f3 o, f3 d, uint32_t pixel) {
+    RayRec r; r.q0 = make_float4(o.x, o.y, o.z, __int_as_float((int)pixel)); r.q1 = make_float4(d.x, d.y, d.z, __int_as_float((int)kRayClosest));
+    r.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return r;
+}
+RT_DEV RayRec ray_shadow(const DevScene& sc, f3 o, f3 d, uint32_t pixel, uint32_t lightTri) {
+    RayRec r; r.q0 = make_float4(o.x, o.y, o.z, __int_as_float((int)pixel)); r.q1 = make_float4(d.x, d.y, d.z, __int_as_float((int)lightTri));
+    r.q2 = make_float4(light_tri_distance(sc, lightTri, o, d), 0.0f, 0.0f, 0.0f); return r;
+}
+RT_DEV RayRec ray_visible(f3 o, f3 d, uint32_t pixel, float dist, float tol) {
+    RayRec r; r.q0 = make_float4(o.x, o.y, o.z, __int_as_float((int)pixel)); r.q1 = make_float4(d.x, d.y, d.z, __int_as_float((int)kRayVisible));
+    r.q2 = make_float4(dist, tol, 0.0f, 0.0f); return r;
+}
+RT_DEV void store_ray(float4* rays, uint32_t index, const RayRec& r) { float4* p = rays + (size_t)index * 3; p[0] = r.q0; p[1] = r.q1; p[2] = r.q2; }
+RT_DEV Hit load_hit(const float4* hits, uint32_t index) { const float4 q = hits[index]; Hit h; h.t = q.x; h.u = q.y; h.v = q.z; h.tri = __float_as_int(q.w); return h; }
+RT_DEV f3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
+RT_DEV float4 f3w(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __int_as_float((int)w)); }
+RT_DEV float4 f3f(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// Slot of this thread's new list entry: ballot + prefix popcount inside a wave, a 4-entry LDS prefix across the waves of the
+// workgroup, ONE atomic on the list counter per workgroup.  Every thread of the workgroup must call it.
+RT_DEV uint32_t block_append(bool live, uint32_t* counter) {
+    __shared__ uint32_t s_cnt[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const unsigned long long mask = __ballot(live);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    const uint32_t n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < wave; ++k) rank += s_cnt[k];
+    if (threadIdx.x == 0u) s_base = n ? atomicAdd(counter, n) : 0u;
+    __syncthreads();
+    const uint32_t slot = s_base + rank;
+    __syncthreads();                                   // s_cnt / s_base are written again by the next call
+    return slot;
+}
+
+// ============================================================ primary rays of techniques 0-6
+// First lines of every PerPixel_* function (e.g. R.cu:565-600): primary ray, sky / directly visible emitter -> finished.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t* pixelList, uint32_t* listCount) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    uint32_t x, y;
+    const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
+    const uint32_t i = x + y * fr.W;
+    bool live = false;
+    if (inside) {
+        const f3 pd = ray_direction(cam, x, y);
+        const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, s_stack + threadIdx.x);
+        fr.payload[i] = pp;
+        if (pp.hitDistance < 0.0f) epilogue(fr, i, rgb1(st.sky));
+        else {
+            const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+            if (length(emission(hm)) > 0.0f) epilogue(fr, i, rgb1(emission(hm))); else live = true;
+        }
+    }
+    const uint32_t slot = block_append(live, listCount);
+    if (live) pixelList[slot] = i;
+}
+
+RT_DEV uint32_t owner_of(const PathIO& io, uint32_t j) {
+    return io.iteration == 0u ? io.pixelList[j] : (uint32_t)__float_as_int(io.raysIn[(size_t)j * io.raysPer * 3].w);
+}
+
+// ============================================================ techniques 0-4 (Renderer.cu:565-1284): sample loop x bounce loop
+// state: S0 = throughput, seed | S1 = radiance, sample | bounce << 16
+template <int TECH>
+RT_DEV bool path_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
+    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+    float4* S = io.state + (size_t)i * io.stateStride;
+    const int nSamples = (TECH == T_BRUTE) ? 1 : (int)st.sampleCount;
+    uint32_t seed; int s = 0, b = 0; f3 T = splat3(1.0f), radiance = splat3(0.0f), ro = splat3(0.0f), rd = splat3(0.0f);
+    bool open = false;                                                     // a sample's path is in flight and needs its next ray
+    if (io.iteration == 0u) seed = i * fr.frameIndex;
+    else {
+        const float4 s0 = S[0], s1 = S[1];
+        T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); radiance = xyz(s1);
+        const uint32_t sb = (uint32_t)__float_as_int(s1.w); s = (int)(sb & 0xFFFFu); b = (int)(sb >> 16);
+        const float4* R = io.raysIn + (size_t)j * 3;
+        ro = xyz(R[0]); rd = xyz(R[1]);
+        const Hit h = load_hit(io.hitsIn, j);
+        if (h.tri < 0) radiance = radiance + T * st.sky;
+        else {
+            const Payload hit = make_hit(sc, ro, rd, h);
+            const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
+            const f3 em = emission(m);
+            if (length(em) > 0.0f) radiance = radiance + T * em;
+            else {
+                const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
+                float primaryRoughness = 0.0f;                              // GGX bounces use the PRIMARY hit's roughness (Renderer.cu:1091-1092)
+                if (TECH == T_GGX) primaryRoughness = load_mat(sc, tri_material(sc, fr.payload[i].objectIndex)).roughness;
+                float bpdf;
+                const f3 bdir = sample_dir<TECH>(nrm3(hit), -rd, m, alb, primaryRoughness, seed, bpdf);
+                const f3 bbrdf = eval_brdf(nrm3(hit), -rd, bdir, alb, m.metallic, m.roughness);
+                const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
+                if (TECH == T_COSINE) bpdf = pdf_cosine(bcos);
+                T = T * ((bbrdf * bcos) / bpdf);
+                ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
+                ++b;
+                open = b < (int)st.maxBounces;
+            }
+        }
+        if (!open) ++s;
+    }
+    if (!open && s < nSamples) {                                           // start the next sample(s) from the primary hit
+        const Payload pp = fr.payload[i];
+        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        const f3 palbedo = sample_albedo(sc, hm, pp.u, pp.v);
+        const f3 pd = ray_direction(cam, x, y);
+        for (; s < nSamples; ++s) {
+            if (TECH != T_BRUTE) seed += (uint32_t)((s + 1) * 27);
+            float pdf;
+            const f3 dir = sample_dir<TECH>(nrm3(pp), -pd, hm, palbedo, hm.roughness, seed, pdf);
+            const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, palbedo, hm.metallic, hm.roughness);
+            const float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
+            if (TECH == T_COSINE) pdf = pdf_cosine(cosT);
+            T = splat3(1.0f) * ((brdf * cosT) / pdf);
+            ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir; b = 0;
+            if (st.maxBounces > 0u) { open = true; break; }
+        }
+    }
+    if (open) {
+        seed += (uint32_t)(((TECH == T_BRUTE) ? 0 : s) + 31 * b);
+        out = ray_closest(ro, rd, i);
+        S[0] = f3w(T, seed); S[1] = f3w(radiance, (uint32_t)s | ((uint32_t)b << 16));
+        return true;
+    }
+    if (TECH != T_BRUTE) radiance = radiance / (float)st.sampleCount;
+    epilogue(fr, i, rgb1(radiance));
+    return false;
+}
+
+// ============================================================ LIGHT_SOURCE_SAMPLING (Renderer.cu:1287-1408): one shadow ray per sample
+// state: S0 = pending contribution T, seed | S1 = radiance, sample
+RT_DEV bool light_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
+    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+    float4* S = io.state + (size_t)i * io.stateStride;
+    uint32_t seed; int s = 0; f3 radiance = splat3(0.0f);
+    if (io.iteration == 0u) seed = i * fr.frameIndex;
+    else {
+        const float4 s0 = S[0], s1 = S[1];
+        const f3 T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); radiance = xyz(s1); s = __float_as_int(s1.w);
+        const uint32_t lightTri = (uint32_t)__float_as_int(io.raysIn[(size_t)j * 3 + 1].w);
+        const float4 hq = io.hitsIn[j];
+        if (hq.x < 0.0f) radiance = radiance + T * st.sky;
+        else if ((uint32_t)__float_as_int(hq.w) == lightTri) {
+            const Mat lm = load_mat(sc, __float_as_int(sc.triPos[(size_t)lightTri * 3].w));
+            if (length(emission(lm)) > 0.0f) radiance = radiance + T * emission(lm);
+        }
+        ++s;
+    }
+    if (s < (int)st.sampleCount) {
+        const Payload pp = fr.payload[i];
+        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+        const f3 pd = ray_direction(cam, x, y);
+        seed += (uint32_t)((s + 1) * 27);
+        const PickedLight pl = pick_light(sc, pos3(pp), seed);
+        const TriGeom g = load_tri(sc, pl.tri);
+        const f3 ep = tri_random_point(g, seed);
+        f3 dir = ep - pos3(pp);
+        const float dist = length(pos3(pp) - ep);
+        dir = dir / dist;
+        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+        const float cx = gmax(dot(dir, nrm3(pp)), 0.0f);
+        const float cy = gmax(dot(-dir, tri_normal(g)), 0.0f);
+        const float triAreaPDF = 1.0f / tri_area(g);
+        const float totalPDF = (pl.pmf * triAreaPDF) * (dist * dist);
+        const f3 T = splat3(1.0f) * (((brdf * cx) * cy) / totalPDF);
+        out = ray_shadow(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, i, pl.tri);
+        S[0] = f3w(T, seed); S[1] = f3w(radiance, (uint32_t)s);
+        return true;
+    }
+    radiance = radiance / (float)st.sampleCount;
+    epilogue(fr, i, rgb1(radiance));
+    return false;
+}
+
+// ============================================================ NEE + BRDF MIS (Renderer.cu:1411-1626): per bounce a shadow ray AND the bounce ray
+// state: S0 = throughput, seed | S1 = radiance, sample | bounce << 16 | S2 = pending direct contribution (added iff the light is visible), pdfBRDF
+RT_DEV bool nee_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& o0, RayRec& o1) {
+    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+    float4* S = io.state + (size_t)i * io.stateStride;
+    const uint32_t maxBounces = st.maxBounces;
+    uint32_t seed; int s = 0; uint32_t bounce = 0; f3 T = splat3(1.0f), radiance = splat3(0.0f), rd = splat3(0.0f); float pdfBRDF = 1.0f;
+    Payload hit;
+    bool open = false;
+    if (io.iteration == 0u) seed = i * fr.frameIndex;
+    else {
+        const float4 s0 = S[0], s1 = S[1], s2 = S[2];
+        T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); radiance = xyz(s1); pdfBRDF = s2.w;
+        const uint32_t sb = (uint32_t)__float_as_int(s1.w); s = (int)(sb & 0xFFFFu); bounce = sb >> 16;
+        const float4* R = io.raysIn + (size_t)j * io.raysPer * 3;
+        const uint32_t lightTri = (uint32_t)__float_as_int(R[1].w);
+        const float4 sh = io.hitsIn[(size_t)j * io.raysPer];
+        if (sh.x > 0.0f && (uint32_t)__float_as_int(sh.w) == lightTri) radiance = radiance + xyz(s2);      // the direct term prepared by the previous step
+        if (maxBounces != 1u) {
+            const f3 ro = xyz(R[3]); rd = xyz(R[4]);
+            const Hit h = load_hit(io.hitsIn, j * 2u + 1u);
+            if (h.tri < 0) radiance = radiance + T * st.sky;
+            else {
+                hit = make_hit(sc, ro, rd, h);
+                const Mat em = load_mat(sc, tri_material(sc, hit.objectIndex));
+                if (length(emission(em)) > 0.0f) {
+                    const TriGeom eg = load_tri(sc, (uint32_t)hit.objectIndex);
+                    const f3 lp2 = tri_random_point(eg, seed);
+                    f3 ld2 = lp2 - pos3(hit);
+                    const float dist2 = length(ld2);
+                    ld2 = ld2 / dist2;
+                    const float cy = gmax(dot(-ld2, tri_normal(eg)), 1e-12f);
+                    const float triAreaPDF = 1.0f / tri_area(eg);
+                    const float lsa = (triAreaPDF * (dist2 * dist2)) / cy;
+                    const float pdfDirect = direct_emitter_pmf(sc, pos3(hit), (uint32_t)hit.objectIndex) * lsa;
+                    const float wB = pdfBRDF / gmax(pdfBRDF + pdfDirect, 1e-12f);
+                    radiance = radiance + (wB * T) * emission(em);
+                } else {
+                    ++bounce;
+                    open = bounce < maxBounces;
+                }
+            }
+        }
+        if (!open) ++s;
+    }
+    if (!open && s < (int)st.sampleCount && maxBounces > 0u) {            // next sample: restart from the primary hit
+        seed += (uint32_t)((s + 1) * 31);
+        T = splat3(1.0f); rd = ray_direction(cam, x, y); hit = fr.payload[i]; pdfBRDF = 1.0f; bounce = 0; open = true;
+    }
+    if (open) {                                                            // top of the bounce loop (R.cu:1452-1570)
+        const Mat mat = load_mat(sc, tri_material(sc, hit.objectIndex));
+        const f3 albedo = sample_albedo(sc, mat, hit.u, hit.v);
+        const PickedLight pl = pick_light(sc, pos3(hit), seed);
+        const TriGeom g = load_tri(sc, pl.tri);
+        const f3 lp = tri_random_point(g, seed);
+        f3 ld = lp - pos3(hit);
+        const float dist = length(ld);
+        ld = ld / dist;
+        f3 C;
+        {
+            const f3 brdf = eval_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
+            const float cx = gmax(dot(ld, nrm3(hit)), 0.0f);
+            const float cy = gmax(dot(-ld, tri_normal(g)), 1e-12f);
+            const float triAreaPDF = 1.0f / tri_area(g);
+            const float lsa = (triAreaPDF * (dist * dist)) / cy;
+            const float pdfDirect = pl.pmf * lsa;
+            const float pdfB = pdf_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
+            const f3 em = emission(load_mat(sc, g.mat));
+            if (maxBounces == 1u) C = (((T * brdf) * cx) * em) / pdfDirect;
+            else { const float wD = pdfDirect / gmax(pdfB + pdfDirect, 1e-12f); C = ((((wD * T) * brdf) * cx) * em) / pdfDirect; }
+        }
+        const f3 origin = pos3(hit) + nrm3(hit) * 1e-12f;
+        o0 = ray_shadow(sc, origin, ld, i, pl.tri);
+        if (maxBounces != 1u) {
+            const f3 nd = sample_brdf(nrm3(hit), -rd, albedo, mat.metallic, mat.roughness, seed, pdfBRDF);
+            pdfBRDF = gmax(pdfBRDF, 1e-12f);
+            const f3 brdf = eval_brdf(nrm3(hit), -rd, nd, albedo, mat.metallic, mat.roughness);
+            const float cosT = dot(nd, nrm3(hit));
+            T = T * ((brdf * cosT) / pdfBRDF);
+            o1 = ray_closest(origin, nd, i);
+        }
+        S[0] = f3w(T, seed); S[1] = f3w(radiance, (uint32_t)s | (bounce << 16)); S[2] = f3f(C, pdfBRDF);
+        return true;
+    }
+    epilogue(fr, i, rgb1(radiance / (float)st.sampleCount));
+    return false;
+}
+
+// ============================================================ ReSTIR GI Part 1 (Renderer.cu:2043-2293)
+// primary rays over the band + halo rows; finished pixels get an empty reservoir, the others go on to the bounce loop
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_gi_primary(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow,
+                                                       uint32_t* pixelList, uint32_t* listCount) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    uint32_t x, y;
+    const bool inside = p1_pixel_of_thread(fr, p1Begin, p1End, extraRow, x, y);
+    const uint32_t i = x + y * fr.W;
+    bool live = false;
+    if (inside) {
+        const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
+        const f3 pd = ray_direction(cam, x, y);
+        const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, s_stack + threadIdx.x);
+        fr.payload[i] = pp;
+        fr.normalCur[i] = oct_encode(nrm3(pp));
+        bool finished = false; f3 finalColor = splat3(0.0f);
+        if (pp.hitDistance < 0.0f) { finished = true; finalColor = st.sky; }
+        else {
+            const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+            if (length(emission(hm)) > 0.0f) { finished = true; finalColor = emission(hm); }
+        }
+        if (finished) {
+            GIRes R; gi_reset(R);
+            fr.gi[i] = R; fr.depth[i] = pp.hitDistance;
+            if (inBand) epilogue(fr, i, rgb1(finalColor));
+        } else live = true;
+    }
+    const uint32_t slot = block_append(live, listCount);
+    if (live) pixelList[slot] = i;
+}
+
+// state: S0 = throughput, seed | S1 = Lo, bounce | S2 = sample point, original seed | S3 = sample normal
+// returns true while the bounce path needs another ray; `toPart2` = the pixel's reservoir is final and the pixel is inside the band
+RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out, bool& toPart2) {
+    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+    float4* S = io.state + (size_t)i * io.stateStride;
+    const Payload pp = fr.payload[i];
+    uint32_t seed, originalSeed; int b = 0;
+    f3 T = splat3(1.0f), Lo = splat3(0.0f), samplePoint = splat3(0.0f), sampleNormal = splat3(0.0f), ro, rd;
+    bool open;
+    if (io.iteration == 0u) {
+        seed = i * (fr.frameIndex + 1u + st.randSeed);
+        originalSeed = seed;
+        const f3 pd = ray_direction(cam, x, y);
+        const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+        const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
+        float pdf;
+        const f3 dir = sample_brdf(nrm3(pp), -pd, albedo, hm.metallic, hm.roughness, seed, pdf);
+        const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
+        const float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
+        T = T * ((brdf * cosT) / pdf);
+        ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
+        open = st.maxBounces > 0u;
+    } else {
+        const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
+        T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); Lo = xyz(s1); b = __float_as_int(s1.w);
+        samplePoint = xyz(s2); originalSeed = (uint32_t)__float_as_int(s2.w); sampleNormal = xyz(s3);
+        const float4* R = io.raysIn + (size_t)j * 3;
+        ro = xyz(R[0]); rd = xyz(R[1]);
+        const Hit h = load_hit(io.hitsIn, j);
+        const Payload hit = (h.tri < 0) ? make_miss() : make_hit(sc, ro, rd, h);
+        if (b == 0) { samplePoint = pos3(hit); sampleNormal = nrm3(hit); }
+        open = false;
+        if (hit.hitDistance < 0.0f) Lo = Lo + T * st.sky;
+        else {
+            const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
+            const f3 em = emission(m);
+            if (length(em) > 0.0f) Lo = Lo + T * em;
+            else {
+                const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
+                float bpdf;
+                const f3 bdir = sample_brdf(nrm3(hit), -rd, alb, m.metallic, m.roughness, seed, bpdf);
+                const f3 bbrdf = eval_brdf(nrm3(hit), -rd, bdir, alb, m.metallic, m.roughness);
+                const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
+                T = T * ((bbrdf * bcos) / bpdf);
+                ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
+                ++b;
+                open = b < (int)st.maxBounces;
+            }
+        }
+    }
+    toPart2 = false;
+    if (open) {
+        seed += (uint32_t)(31 * b);
+        out = ray_closest(ro, rd, i);
+        S[0] = f3w(T, seed); S[1] = f3w(Lo, (uint32_t)b); S[2] = f3w(samplePoint, originalSeed); S[3] = f3f(sampleNormal, 0.0f);
+        return true;
+    }
+    // the path is complete: initial reservoir (R.cu:2186-2228), temporal reuse (:2230-2290)
+    GIRes R; gi_reset(R);
+    {
+        GISample sm; sm.seed = originalSeed;
+        sm.vp[0] = pp.px; sm.vp[1] = pp.py; sm.vp[2] = pp.pz;
+        const f2 vn = oct_encode(nrm3(pp)); sm.vn[0] = vn.x; sm.vn[1] = vn.y;
+        sm.sp[0] = samplePoint.x; sm.sp[1] = samplePoint.y; sm.sp[2] = samplePoint.z;
+        const f2 sn = oct_encode(sampleNormal); sm.sn[0] = sn.x; sm.sn[1] = sn.y;
+        sm.Lo[0] = Lo.x; sm.Lo[1] = Lo.y; sm.Lo[2] = Lo.z; sm.pdf = 0.0f;
+        const float len = length(Lo);
+        gi_update(R, sm, len, 1u, len, seed);
+        R.W = R.s.pdf > 0.0f ? ((1.0f / R.s.pdf) * R.wSum) / (float)R.M : 0.0f;
+    }
+    if (st.useTemporal) {
+        uint32_t prow;
+        const uint32_t prevIdx = prev_pixel(cam, pos3(pp), prow);
+        const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
+        GIRes prev = fr.giPrev[prevIdx];
+        const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99 && prow >= fr.histBegin && prow < fr.histEnd;
+        const f3 plo = lo3(prev.s);
+        if (valid && prev.M > 0u && dot(plo, plo) > 0.0f) {
+            GIRes Tm = R;
+            const uint32_t lim = st.historyLimit * R.M;
+            prev.M = (lim < prev.M) ? lim : prev.M;
+            const float pdf = length(plo);
+            gi_update(Tm, prev.s, (pdf * prev.W) * (float)prev.M, prev.M, pdf, seed);
+            Tm.W = Tm.s.pdf > 0.0f ? Tm.s.pdf / ((float)Tm.M * Tm.s.pdf) : 0.0f;
+            gi_reset(R);
+            gi_merge(R, Tm, Tm.s.pdf, seed);
+        }
+    }
+    fr.gi[i] = R;
+    toPart2 = (y >= fr.rowBegin && y < fr.rowEnd);          // replaces the reference's image sentinel (R.cu:2746-2750 / :2787): Part 2 runs on a list
+    return false;
+}
+
+// ============================================================ ReSTIR GI Part 2 (Renderer.cu:2295-2387): one visibility ray per accepted neighbour
+// state: S0..S4 = the reservoir being merged (18 floats), seed, neighbour counter | S5 = Z, neighbour pixel, its pdf
+RT_DEV void save_gires(float4* S, const GIRes& R, uint32_t seed, uint32_t n) {
+    S[0] = make_float4(R.s.vp[0], R.s.vp[1], R.s.vp[2], R.s.vn[0]);
+    S[1] = make_float4(R.s.vn[1], R.s.sp[0], R.s.sp[1], R.s.sp[2]);
+    S[2] = make_float4(R.s.sn[0], R.s.sn[1], R.s.Lo[0], R.s.Lo[1]);
+    S[3] = make_float4(R.s.Lo[2], __int_as_float((int)R.s.seed), R.s.pdf, R.W);
+    S[4] = make_float4(__int_as_float((int)R.M), R.wSum, __int_as_float((int)seed), __int_as_float((int)n));
+}
+RT_DEV void load_gires(const float4* S, GIRes& R, uint32_t& seed, uint32_t& n) {
+    const float4 a = S[0], b = S[1], c = S[2], d = S[3], e = S[4];
+    R.s.vp[0] = a.x; R.s.vp[1] = a.y; R.s.vp[2] = a.z; R.s.vn[0] = a.w;
+    R.s.vn[1] = b.x; R.s.sp[0] = b.y; R.s.sp[1] = b.z; R.s.sp[2] = b.w;
+    R.s.sn[0] = c.x; R.s.sn[1] = c.y; R.s.Lo[0] = c.z; R.s.Lo[1] = c.w;
+    R.s.Lo[2] = d.x; R.s.seed = (uint32_t)__float_as_int(d.y); R.s.pdf = d.z; R.W = d.w;
+    R.M = (uint32_t)__float_as_int(e.x); R.wSum = e.y; seed = (uint32_t)__float_as_int(e.z); n = (uint32_t)__float_as_int(e.w);
+}
+RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
+    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+    float4* S = io.state + (size_t)i * io.stateStride;
+    const Payload pp = fr.payload[i];
+    GIRes R; uint32_t seed, n = 0, Z = 0;
+    if (io.iteration == 0u) {
+        R = fr.gi[i];
+        seed = i * (fr.frameIndex + 213u + st.randSeed);
+        if (st.useSpatial) { const float plen = length(lo3(R.s)); Z = plen > 0.0f ? R.M : 0u; }
+    } else {
+        load_gires(S, R, seed, n);
+        const float4 s5 = S[5];
+        Z = (uint32_t)__float_as_int(s5.x);
+        const uint32_t ni = (uint32_t)__float_as_int(s5.y);
+        float pdf = s5.z;
+        const GIRes N = fr.gi[ni];
+        if (!(io.hitsIn[j].x != 0.0f)) pdf = 0.0f;                          // R.cu:2356-2366: the neighbour's sample point is not visible
+        gi_merge(R, N, pdf, seed);
+        ++n;
+    }
+    if (st.useSpatial) {
+        for (; n < st.numNeighbors; ++n) {
+            const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+            const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
+            const GIRes N = fr.gi[ni];
+            const float nlen = length(lo3(N.s));
+            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906 || nlen == 0.0f) continue;
+            Z += N.M;
+            f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
+            const f3 sn = oct_decode(sne);
+            const f3 nvp = mk3(N.s.vp[0], N.s.vp[1], N.s.vp[2]), nsp = mk3(N.s.sp[0], N.s.sp[1], N.s.sp[2]);
+            const f3 rvp = mk3(R.s.vp[0], R.s.vp[1], R.s.vp[2]);
+            const f3 dQ = normalize(nvp - nsp);
+            const float cosQ = dot(sn, dQ);
+            const f3 dR = normalize(rvp - nsp);
+            const float cosR = dot(sn, dR);
+            const float jl = cosQ > 0.0f ? cosR / cosQ : 0.0f;
+            const float distQ = length(nvp - nsp), distR = length(rvp - nsp);
+            const float jr = distR > 0.0f ? (distQ * distQ) / (distR * distR) : 0.0f;
+            const float jac = jl * jr;
+            const float pdf = jac > 0.0f ? nlen / jac : 0.0f;
+            const float tol = gmax(1e-4f, distR * 1e-3f);
+            out = ray_visible(nsp, dR, i, distR, tol);
+            save_gires(S, R, seed, n);
+            S[5] = make_float4(__int_as_float((int)Z), __int_as_float((int)ni), pdf, 0.0f);
+            return true;
+        }
+        R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;
+    }
+    const f3 radiance = lo3(R.s) * R.W;
+    fr.depth[i] = pp.hitDistance;
+    fr.giPrev[i] = R;
+    epilogue(fr, i, rgb1(radiance));
+    return false;
+}
+
+// ============================================================ the shade kernel: one thread per live path, grid-stride over the list
+template <int TECH>
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, PathIO io) {
+    const uint32_t count = *io.countIn;
+    for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < count; base += gridDim.x * (uint32_t)kBlock) {
+        const uint32_t j = base + threadIdx.x;
+        bool live = false, toPart2 = false;
+        RayRec r0, r1;
+        if (j < count) {
+            if (TECH == T_LIGHT) live = light_step(sc, cam, fr, st, io, j, r0);
+            else if (TECH == T_NEE) live = nee_step(sc, cam, fr, st, io, j, r0, r1);
+            else if (TECH == T_GI1) live = gi1_step(sc, cam, fr, st, io, j, r0, toPart2);
+            else if (TECH == T_GI2) live = gi2_step(sc, cam, fr, st, io, j, r0);
+            else live = path_step<(TECH <= T_BRDF ? TECH : T_BRUTE)>(sc, cam, fr, st, io, j, r0);
+        }
+        const uint32_t slot = block_append(live, io.countOut);
+        if (live) {
+            store_ray(io.raysOut, slot * io.raysPer, r0);
+            if (TECH == T_NEE && io.raysPer == 2u) store_ray(io.raysOut, slot * 2u + 1u, r1);
+        }
+        if (TECH == T_GI1) {
+            const uint32_t slot2 = block_append(toPart2, io.part2Count);
+            if (toPart2) io.part2List[slot2] = owner_of(io, j);
+        }
+    }
+}
+
+}  // namespace rt

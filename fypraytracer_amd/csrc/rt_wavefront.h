@@ -177,14 +177,19 @@ __global__ __launch_bounds__(kBlock) void k_di_sort_scatter(ShadowQueue q) {
 // per-lane in-flight ray of the persistent trace kernel
 struct LaneRay {
     f3 o, d; RayPk pk; float tL, cut; uint32_t lightTri, task;      // task: queue slot; pixel index and the two candidate radiances
-    int32_t cur; int top; int32_t hitTri; bool closestMode; uint32_t nBox, nTri;   // are re-read from it at the epilogue (saves 9 VGPRs)
+    int32_t cur; int top; int32_t hitTri; bool closestMode; uint32_t nBox, nTri, nNode;   // are re-read from it at the epilogue (saves 9 VGPRs)
 };
 
 RT_DEV void lane_push(int32_t* lds, int& top, int32_t v) { lds[top * kBlock] = v; ++top; }
 RT_DEV int32_t lane_pop(int32_t* lds, int& top) { --top; return lds[top * kBlock]; }
 
-__global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame fr, ShadowQueue q) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+// register budget of the persistent trace kernels: 6 waves per SIMD (80 VGPRs) — with the 22 KB LDS stack of the bench tree 6 workgroups
+// fit a CU, and each resident workgroup more buys 4-5 % (profiles/README.md); the compiler's own allocation lands a few registers above
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES __attribute__((amdgpu_waves_per_eu(6)))
+#endif
+template <bool COUNT>
+RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const ShadowQueue& q, int32_t* s_stack) {
     int32_t* lds = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = q.counters[0];
@@ -201,8 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
     const uint32_t first = share < want1 ? (share < 16u ? 16u : share) : want1;
     const uint32_t dynBase = nWaves * first;
     const bool hasDyn = dynBase < total;                           // otherwise the static chunks cover the whole queue: no atomics at all
-    const bool counting = sc.rayCounter != nullptr;
-    LaneRay r; r.cur = kExit; r.top = 0;
+    LaneRay r; r.cur = kExit; r.top = 0; r.nBox = 0; r.nTri = 0; r.nNode = 0;
     bool active = false;                                           // lane owns a ray that is still being traced
     bool pending = false;                                          // lane's ray is finished, its pixel epilogue not yet run
     uint32_t outcome = 0;                                          // of the finished ray: 0 occluded, 1 light visible, 2 nothing hit (sky)
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 r.tL = r.closestMode ? 3.402823466e+38f : tL;
                 r.cut = r.tL * 1.000001f;
                 r.hitTri = r.closestMode ? -1 : (int32_t)r.lightTri;
-                r.nBox = 0; r.nTri = 1;
+                if (COUNT) { r.nBox = 0; r.nTri = 1; r.nNode = 0; }
                 r.top = 0; lane_push(lds, r.top, kExit);
                 r.cur = (sc.triCount == 0 || ray_not_finite(r.o, r.d)) ? kExit : sc.rootRef;   // (a non-finite ray also fails the light test above: closest mode, miss)
                 active = true;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
         while (true) {
             // inner nodes
             while (active && r.cur >= 0) {
-                { Stack st; st.lds = lds; st.top = r.top; r.cur = node_step(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, counting); r.top = st.top; }
+                { Stack st; st.lds = lds; st.top = r.top; r.cur = node_step<COUNT>(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, r.nNode); r.top = st.top; }
                 if ((uint32_t)__popcll(__ballot(r.cur >= 0)) < sc.nodeQuorum) break;
             }
             // leaves
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     const uint32_t id = (uint32_t)__float_as_int(c.y);
                     if (!r.closestMode && id == r.lightTri) continue;
-                    if (counting) r.nTri += 1;
+                    if (COUNT) r.nTri += 1;
                     const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
                     const f3 hh = cross(r.d, e2);
                     const float det = dot(e1, hh), f = 1.0f / det;
@@ -318,11 +322,12 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
                 if (r.hitTri == (int32_t)r.lightTri) outcome = 1u;                      // R.cu:2016-2027: Lvis
                 else if (r.closestMode && r.hitTri < 0) outcome = 2u;                   // R.cu:2028-2031: Lsky
                 pending = true;
-                if (counting) {
+                if (COUNT) {
                     // same totals as trace_shadow: the fallback counts its light test, then a full closest-hit ray
                     atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)r.nBox);
                     atomicAdd(sc.rayCounter + 2, (unsigned long long)r.nTri);
                     atomicAdd(sc.rayCounter + 3, (unsigned long long)((r.closestMode && r.hitTri < 0) ? 0 : 1));
+                    atomicAdd(sc.rayCounter + 4, (unsigned long long)r.nNode);
                 }
                 active = false;
             }
@@ -331,6 +336,143 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_trace(DevScene sc, DevFrame
             if (more && (64u - (uint32_t)__popcll(act)) >= q.refillLanes) break;
         }
     }
+}
+
+template <bool COUNT> __global__ void k_di_part2_trace(DevScene sc, DevFrame fr, ShadowQueue q);
+template <> __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void k_di_part2_trace<false>(DevScene sc, DevFrame fr, ShadowQueue q) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    di_part2_trace_body<false>(sc, fr, q, s_stack);
+}
+template <> __global__ __launch_bounds__(kBlock) void k_di_part2_trace<true>(DevScene sc, DevFrame fr, ShadowQueue q) {   // instrumented: no register cap
+    extern __shared__ int32_t s_stack[];
+    di_part2_trace_body<true>(sc, fr, q, s_stack);
+}
+
+// =====================================================================================================================
+// Generic ray queue of the wavefront path engine (rt_paths.h): every technique but ReSTIR DI runs as
+//   primary kernel -> [ shade step -> k_trace_rays ] x N -> last shade step,
+// where a shade step (one thread per live path, no traversal state) consumes the results of the rays it emitted in the previous
+// step and emits the next ones, compacted with ballot + prefix popcount.  A ray record is three quads:
+//   q0 = origin.xyz | owner pixel      q1 = direction.xyz | mode      q2 = mode arguments
+//   mode = kRayClosest : closest hit                                   -> result (t, u, v, triangle | -1)
+//          kRayVisible : ReSTIR GI visibility query, q2 = (dist, tol)  -> result.x = 1 iff a hit lies in [dist - tol, dist + tol] and none before
+//          otherwise   : shadow ray towards light triangle `mode`; q2.x = distance to the light triangle along the ray, computed by the
+//                        emitting shade step at full lane utilisation (<= 0: the ray misses its own light -> exact closest-hit fallback)
+//                                                                       -> result (hitDistance | -1, -, -, objectIndex) == trace_shadow()
+// k_trace_rays: persistent waves, every lane owns one in-flight ray, idle lanes are refilled from the wave's claimed chunk of the
+// queue (same guided self-scheduling as the ReSTIR DI trace kernel); it holds nothing but traversal state: a refill is two loads
+// and three reciprocals, a finished ray is one 16-byte store.
+constexpr uint32_t kRayClosest = 0xFFFFFFFEu, kRayVisible = 0xFFFFFFFDu;
+struct TraceQueue {
+    const float4* rays; float4* hits; const uint32_t* count; uint32_t raysPer; uint32_t* head;
+    uint32_t chunk, refillLanes, staticChunks, minChunk;
+};
+
+template <bool COUNT>
+RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_stack) {
+    int32_t* lds = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = *q.count * q.raysPer;
+    const uint32_t nWaves = gridDim.x * (uint32_t)(kBlock / 64), myWave = blockIdx.x * (uint32_t)(kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t share = (total + nWaves - 1u) / nWaves;
+    const uint32_t chunk = q.chunk, want1 = chunk * q.staticChunks;
+    const uint32_t first = share < want1 ? (share < 16u ? 16u : share) : want1;
+    const uint32_t dynBase = nWaves * first;
+    const bool hasDyn = dynBase < total;
+    f3 o = splat3(0.0f), d = splat3(0.0f); RayPk pk = make_raypk(o, 1.0f, 1.0f, 1.0f);
+    float tL = 0.0f, cut = 0.0f, hu = 0.0f, hv = 0.0f; uint32_t mode = kRayClosest, task = 0; int32_t cur = kExit, hitTri = -1; int top = 0;
+    bool closestMode = true;
+    uint32_t nBox = 0, nTri = 0, nNode = 0;
+    bool active = false;
+    bool more = total != 0u;
+    uint32_t chunkNext = myWave * first < total ? myWave * first : total;
+    uint32_t chunkEnd = (myWave + 1u) * first < total ? (myWave + 1u) * first : total;
+    while (true) {
+        const unsigned long long idle = __ballot(!active);
+        if (more && (uint32_t)__popcll(idle) >= q.refillLanes) {
+            if (chunkNext >= chunkEnd && hasDyn) {
+                uint32_t base = 0;
+                uint32_t size = (total - chunkEnd) / nWaves;
+                size = size < q.minChunk ? q.minChunk : (size > chunk ? chunk : size);
+                if (lane == 0u) base = dynBase + atomicAdd(q.head, size);
+                base = (uint32_t)__shfl((int)base, 0);
+                chunkNext = base < total ? base : total;
+                chunkEnd = (base + size < total) ? base + size : total;
+            }
+            const uint32_t slot = chunkNext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t want = (uint32_t)__popcll(idle), avail = chunkEnd - chunkNext;
+            chunkNext += (want < avail) ? want : avail;
+            more = chunkNext < chunkEnd || (hasDyn && chunkEnd < total);
+            if (!active && slot < chunkEnd) {
+                task = slot;
+                const float4* t = q.rays + (size_t)task * 3;
+                const float4 t0 = t[0], t1 = t[1], t2 = t[2];
+                o = mk3(t0.x, t0.y, t0.z); d = mk3(t1.x, t1.y, t1.z); mode = (uint32_t)__float_as_int(t1.w);
+                pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+                hitTri = -1; hu = 0.0f; hv = 0.0f; closestMode = true; tL = 3.402823466e+38f;
+                if (mode == kRayVisible) { closestMode = false; hu = t2.x - t2.y; tL = t2.x + t2.y; }     // hu = dist - tol, interval end = dist + tol; hv: 0 nothing yet, 1 found, -1 blocked
+                else if (mode != kRayClosest && t2.x > 0.0f) { closestMode = false; tL = t2.x; hitTri = (int32_t)mode; }
+                cut = tL * 1.000001f;
+                if (COUNT) { nBox = 0; nNode = 0; nTri = (mode != kRayClosest && mode != kRayVisible) ? 1u : 0u; }
+                top = 0; lane_push(lds, top, kExit);
+                cur = (sc.triCount == 0 || ray_not_finite(o, d)) ? kExit : sc.rootRef;
+                active = true;
+            }
+        }
+        if (__ballot(active) == 0ull) { if (!more) break; else continue; }
+        while (true) {
+            while (active && cur >= 0) {
+                { Stack st; st.lds = lds; st.top = top; cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode); top = st.top; }
+                if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+            }
+            if (active && cur < 0 && cur != kExit) {
+                const uint32_t code = (uint32_t)~cur, firstTri = code >> 2, cnt = (code & 3u) + 1u;
+                bool done = false;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4* tp = sc.leafTris + (size_t)(firstTri + k) * 3;
+                    if (!closestMode && (uint32_t)__float_as_int(tp[2].y) == mode) continue;     // a shadow ray does not test its own light again
+                    float t, u, v; uint32_t id;
+                    if (COUNT) nTri += 1;
+                    if (!tri_test(tp, o, d, t, u, v, id)) continue;
+                    if (mode == kRayVisible) {
+                        if (t < hu) { hv = -1.0f; done = true; break; }
+                        if (t <= tL) hv = 1.0f;
+                    } else if (t < tL) {
+                        hitTri = (int32_t)id; tL = t;
+                        if (closestMode) { cut = t * 1.000001f; hu = u; hv = v; }
+                        else { done = true; break; }
+                    }
+                }
+                cur = done ? kExit : lane_pop(lds, top);
+            }
+            if (active && cur == kExit) {
+                float4 res;
+                if (mode == kRayVisible) res = make_float4(hv > 0.0f ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+                else res = make_float4(hitTri < 0 ? -1.0f : tL, hu, hv, __int_as_float(hitTri));
+                q.hits[task] = res;
+                if (COUNT) {
+                    atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
+                    atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri);
+                    atomicAdd(sc.rayCounter + 3, (unsigned long long)((mode == kRayVisible) ? (hv > 0.0f ? 1 : 0) : (hitTri < 0 ? 0 : 1)));
+                    atomicAdd(sc.rayCounter + 4, (unsigned long long)nNode);
+                }
+                active = false;
+            }
+            const unsigned long long act = __ballot(active);
+            if (act == 0ull) break;
+            if (more && (64u - (uint32_t)__popcll(act)) >= q.refillLanes) break;
+        }
+    }
+}
+
+template <bool COUNT> __global__ void k_trace_rays(DevScene sc, TraceQueue q);
+template <> __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void k_trace_rays<false>(DevScene sc, TraceQueue q) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    trace_rays_body<false>(sc, q, s_stack);
+}
+template <> __global__ __launch_bounds__(kBlock) void k_trace_rays<true>(DevScene sc, TraceQueue q) {                       // instrumented: no register cap
+    extern __shared__ int32_t s_stack[];
+    trace_rays_body<true>(sc, q, s_stack);
 }
 
 }  // namespace rt

@@ -147,6 +147,8 @@ typedef struct fyprt_frame_stats {
     uint64_t hits;          /* rays that found a triangle      }                                               */
     uint64_t part_rays[4], part_box_tests[4], part_tri_tests[4], part_hits[4];   /* the same, per launch */
     uint32_t launches;
+    uint64_t node_visits;   /* 64-byte node records fetched (one per visit; box_tests counts the valid children tested in them) */
+    uint64_t part_node_visits[4];
 } fyprt_frame_stats;
 
 /* Buffers readable with fyprt_read_buffer (device -> host, for parity tests). */

@@ -110,7 +110,7 @@ void orc_render(orc_handle* h, const void* settings52, uint32_t row_begin, uint3
     std::memcpy(&R.st, settings52, 52);
     if (row_end > R.fr.H) row_end = R.fr.H;
     Counters c = R.RenderFrame(row_begin, row_end, halo);
-    if (counters_out) { counters_out[0] = c.rays; counters_out[1] = c.boxTests; counters_out[2] = c.triTests; counters_out[3] = c.hits; }
+    if (counters_out) { counters_out[0] = c.rays; counters_out[1] = c.boxTests; counters_out[2] = c.triTests; counters_out[3] = c.hits; counters_out[4] = c.nodeVisits; }
 }
 
 // which follows enum fyprt_buffer; returns bytes copied (0 on error)
@@ -165,7 +165,7 @@ void orc_trace(orc_handle* h, const float* origin3, const float* dir3, void* pay
     Ray r{v3(origin3[0], origin3[1], origin3[2]), v3(dir3[0], dir3[1], dir3[2])};
     Counters c; Payload p = h->R().tracer.Trace(r, c);
     std::memcpy(payload40, &p, 40);
-    if (counters_out) { counters_out[0] = c.rays; counters_out[1] = c.boxTests; counters_out[2] = c.triTests; counters_out[3] = c.hits; }
+    if (counters_out) { counters_out[0] = c.rays; counters_out[1] = c.boxTests; counters_out[2] = c.triTests; counters_out[3] = c.hits; counters_out[4] = c.nodeVisits; }
 }
 void orc_ray_direction(orc_handle* h, uint32_t x, uint32_t y, float* out3) { vec3 d = h->R().RayDirection(x, y); out3[0] = d.x; out3[1] = d.y; out3[2] = d.z; }
 

@@ -47,7 +47,7 @@ struct ProductTracer : Tracer {
         const PNode& n = nodes[node];
         const uint32_t cnt = n.meta & 7u, levels = n.meta >> 3;
         const uint32_t allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu;
-        c.boxTests += (uint64_t)__builtin_popcount(allow & ((1u << cnt) - 1u));
+        c.boxTests += (uint64_t)__builtin_popcount(allow & ((1u << cnt) - 1u)); c.nodeVisits++;
         const float o[3] = {ox, oy, oz}, inv[3] = {ix, iy, iz};
         float A[3], B[3];
         for (int a = 0; a < 3; ++a) { A[a] = pow2e(n.ex[a]) * inv[a]; B[a] = (n.origin[a] - o[a]) * inv[a]; }

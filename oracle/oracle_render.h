@@ -54,7 +54,7 @@ enum { BRUTE_FORCE, UNIFORM_SAMPLING, COSINE_WEIGHTED_SAMPLING, GGX_SAMPLING, BR
 
 struct Camera { mat4 projection, view, prevProjection, prevView, inverseProjection, inverseView; vec3 position; uint32_t width, height; };
 
-struct Counters { uint64_t rays = 0, boxTests = 0, triTests = 0, hits = 0; };
+struct Counters { uint64_t rays = 0, boxTests = 0, triTests = 0, hits = 0, nodeVisits = 0; };
 
 // ---- reservoirs
 static inline bool DI_Update(DIReservoir& r, uint32_t cand, float weight, uint32_t count, float pdf, uint32_t& seed) { // DI.cu:3-36
@@ -741,7 +741,7 @@ struct Renderer {
                     for (uint32_t x = x0; x < x1; ++x) fn(x, y, local);
                 }
                 #pragma omp critical
-                { total.rays += local.rays; total.boxTests += local.boxTests; total.triTests += local.triTests; total.hits += local.hits; }
+                { total.rays += local.rays; total.boxTests += local.boxTests; total.triTests += local.triTests; total.hits += local.hits; total.nodeVisits += local.nodeVisits; }
             }
         };
         if (tech == RESTIR_DI || tech == RESTIR_GI) {

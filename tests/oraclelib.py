@@ -126,9 +126,9 @@ class Oracle:
 
     def render(self, settings, rows=None, halo=0):
         y0, y1 = rows if rows else (0, self.height)
-        cnt = (C.c_uint64 * 4)()
+        cnt = (C.c_uint64 * 5)()
         self.lib.orc_render(self.h, C.byref(settings), y0, y1, halo, cnt)
-        return {"rays": cnt[0], "box_tests": cnt[1], "tri_tests": cnt[2], "hits": cnt[3]}
+        return {"rays": cnt[0], "box_tests": cnt[1], "tri_tests": cnt[2], "hits": cnt[3], "node_visits": cnt[4]}
 
     def read_buffer(self, which):
         dt = capi.BUFFER_DTYPES[which]
@@ -167,6 +167,6 @@ class Oracle:
         o = np.asarray(origin, dtype=np.float32)
         d = np.asarray(direction, dtype=np.float32)
         p = np.zeros(1, dtype=capi.PAYLOAD_DTYPE)
-        cnt = (C.c_uint64 * 4)()
+        cnt = (C.c_uint64 * 5)()
         self.lib.orc_trace(self.h, o.ctypes.data, d.ctypes.data, p.ctypes.data, cnt)
-        return p[0], {"box_tests": cnt[1], "tri_tests": cnt[2]}
+        return p[0], {"box_tests": cnt[1], "tri_tests": cnt[2], "node_visits": cnt[4]}

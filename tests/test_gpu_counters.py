@@ -1,4 +1,4 @@
-"""The device-side instrumentation (rays / box tests / triangle tests / hits, fyprt_set_ray_counting)
+"""The device-side instrumentation (rays / node visits / box tests / triangle tests / hits, fyprt_set_ray_counting)
 must equal the oracle's instrumented restatement of the same traversal — these counts define the
 algorithmic bytes of the roofline, so they are checked exactly."""
 import pytest
@@ -28,7 +28,8 @@ def test_counters_match_oracle(oracle_built, tech):
         st.rand_seed = f + 1
         g = ctx.render(st)
         o = orc.render(st)
-        assert (g.rays, g.box_tests, g.tri_tests, g.hits) == (o["rays"], o["box_tests"], o["tri_tests"], o["hits"])
+        assert (g.rays, g.box_tests, g.tri_tests, g.hits, g.node_visits) == (o["rays"], o["box_tests"], o["tri_tests"], o["hits"], o["node_visits"])
+        assert sum(g.part_node_visits) == g.node_visits and 0 < g.node_visits < g.box_tests
     if tech == capi.RESTIR_DI:
         assert g.part_rays[0] == W * H                 # one primary ray per pixel in Part 1
         assert sum(g.part_rays) == g.rays              # Part 2's rays are counted in its trace launch
