@@ -139,7 +139,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("FYPRT_LIB", LIB_PATH))     # FYPRT_LIB: an alternative build (A/B experiments)
     if not p.exists():
         raise FyprtError(f"HIP extension not built: {p} is missing. Run `python __graft_entry__.py build` "
                          f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")

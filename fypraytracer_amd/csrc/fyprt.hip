@@ -622,7 +622,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
     int launches = 0;
     // ---- wavefront path engine (rt_paths.h): primary kernel, then per step one shade launch + one persistent trace launch
-    struct StageRun { int stage; uint32_t steps, raysPer, stride; const uint32_t* pixelList; uint32_t* cnt; uint32_t* heads; uint32_t* part2List; uint32_t* part2Count; int counterPart; };
+    struct StageRun { int stage; uint32_t steps, raysPer, stride; const uint32_t* pixelList; uint32_t* cnt; uint32_t* heads; uint32_t* part2List; uint32_t* part2Count; int counterPart; uint32_t* misCounts; };
     auto run_stage = [&](const StageRun& r) -> int {
         const shade_kernel_t shade = shade_kernel(r.stage);
         const dim3 shadeGrid((uint32_t)(c->numCUs * 8));
@@ -640,8 +640,15 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             io.pixelList = r.pixelList; io.raysIn = c->wfRays[it & 1u].p; io.hitsIn = c->wfHits[it & 1u].p; io.countIn = r.cnt + it;
             io.raysOut = c->wfRays[(it + 1u) & 1u].p; io.countOut = r.cnt + it + 1; io.state = c->wfState.p; io.stateStride = r.stride;
             io.iteration = it; io.raysPer = r.raysPer; io.part2List = r.part2List; io.part2Count = r.part2Count;
+            // NEE's MIS list reuses the primary kernel's pixel list, which only step 0 reads (and step 0 has no ray results, hence no MIS entries)
+            io.misList = c->wfPixels.p; io.misCount = r.misCounts ? r.misCounts + it : nullptr;
             hipLaunchKernelGGL(shade, shadeGrid, block, 0, c->stream, c->dsc, c->dcam, fr, st, io);
+            if (r.stage == T_NEE && it > 0u)                         // NEE: emitter-hit MIS for the few paths that need it (may add to the pick list)
+                hipLaunchKernelGGL(k_nee_mis, dim3((uint32_t)c->numCUs), block, 0, c->stream, c->dsc, c->dcam, fr, st, (const uint32_t*)io.misList, (const uint32_t*)io.misCount,
+                                   c->wfState.p, r.stride, r.part2List, io.countOut);
             if (it == r.steps) break;                                // the last step only consumes: every path has emitted all its rays
+            if (r.stage == T_NEE)                                    // light pick + ray construction for the listed paths
+                hipLaunchKernelGGL(k_nee_emit, shadeGrid, block, 0, c->stream, c->dsc, st, (const uint32_t*)r.part2List, (const uint32_t*)io.countOut, c->wfState.p, r.stride, io.raysOut, r.raysPer);
             TraceQueue q{};
             q.rays = io.raysOut; q.hits = c->wfHits[(it + 1u) & 1u].p; q.count = io.countOut; q.raysPer = r.raysPer; q.head = r.heads + it + 1;
             q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24);
@@ -665,12 +672,13 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             const uint32_t steps = (tech == FYPRT_LIGHT_SOURCE_SAMPLING) ? nSamples : nSamples * st.maxBounces;
             const uint32_t raysPer = (tech == FYPRT_NEE && st.maxBounces != 1u) ? 2u : 1u;
             const size_t entries = (size_t)(c->rowEnd - c->rowBegin) * c->W, L = (size_t)steps + 2;
-            { const int rc = ensure_paths(c, entries, raysPer, 3, 2 * L); if (rc != FYPRT_OK) return rc; }
-            HIPCHK(c, hipMemsetAsync(c->wfCounters.p, 0, 2 * L * sizeof(uint32_t), c->stream));
+            const uint32_t stride = (tech == FYPRT_NEE) ? 6u : 2u;
+            { const int rc = ensure_paths(c, entries, raysPer, stride, 3 * L); if (rc != FYPRT_OK) return rc; }
+            HIPCHK(c, hipMemsetAsync(c->wfCounters.p, 0, 3 * L * sizeof(uint32_t), c->stream));
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // coherent primary rays
             if (c->countRays) hipLaunchKernelGGL(k_primary<true>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
             else hipLaunchKernelGGL(k_primary<false>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
-            StageRun r{tech, steps, raysPer, 3u, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, nullptr, nullptr, 0};
+            StageRun r{tech, steps, raysPer, stride, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, (tech == FYPRT_NEE) ? c->wfPixels2.p : nullptr, nullptr, 0, (tech == FYPRT_NEE) ? c->wfCounters.p + 2 * L : nullptr};
             { const int rc = run_stage(r); if (rc != FYPRT_OK) return rc; }
             launches = 1;
             break;
@@ -696,10 +704,10 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                 if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
                 else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0};
+                StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr};
                 { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
-                StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1};
+                StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr};
                 { const int rc = run_stage(r2); if (rc != FYPRT_OK) return rc; }
                 launches = 2;
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;

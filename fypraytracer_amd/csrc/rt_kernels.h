@@ -73,26 +73,29 @@ RT_DEV f3 sample_dir(f3 n, f3 V, const Mat& m, f3 albedo, float ggxRoughness, ui
 }
 
 // ============================================================ light tree (LightTree.cuh:91-117, LightTree.cu, ConeBounds.cuh:47-87)
-RT_DEV float cone_theta_to_box(const DevLTNode& c, f3 p) {
-    // The reference takes max_k acos(clamp(dot_k)) over the 8 box corners (ConeBounds.cuh:47-87).  acos_f is monotone
-    // non-increasing over every float in [-1, 1] (exhaustive check: tests/test_oracle_math.py), so that maximum is
-    // acos_f(min_k clamp(dot_k)) bit for bit: one binary64 acos per cluster instead of eight.  NaN corners are skipped by
-    // fmaxf there and by fminf here; the identity of the maximum (0) is acos_f(1).
-    const f3 axis = normalize(mk3(c.centroid[0], c.centroid[1], c.centroid[2]) - p);
+// LightTreeNode importance (LightTree.cuh:91-117) with FindConeThatEnvelopsAABBFromPoint (ConeBounds.cuh:47-87) inlined.
+//  * The reference takes max_k acos(clamp(dot_k)) over the 8 box corners.  acos_f is monotone non-increasing over every float in
+//    [-1, 1] (exhaustive check: tests/test_oracle_math.py), so that maximum is acos_f(min_k clamp(dot_k)) bit for bit: one binary64
+//    acos per cluster instead of eight.  NaN corners are skipped by fmaxf there and by fminf here; the identity of the maximum (0)
+//    is acos_f(1).
+//  * The cone axis normalize(centroid - p) and the direction normalize(p - centroid) of the importance are each other's exact
+//    negation (x - y == -(y - x), squares and the reciprocal square root are the same numbers), and d2 is the squared length the
+//    normalisation computes anyway: one normalisation instead of two, every value bitwise what the reference computes.
+RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
+    const f3 toC = mk3(c.centroid[0], c.centroid[1], c.centroid[2]) - spPos;
+    const float dd = dot(toC, toC);
+    const float inv = 1.0f / __builtin_sqrtf(dd);
+    const f3 axis = toC * inv;                                  // == normalize(centroid - p)
     float minDot = 1.0f;
-#pragma unroll
+#pragma unroll              // eight independent sqrt / divide chains in flight: leaving the loop rolled costs 20 % of the NEE frame
     for (int k = 0; k < 8; ++k) {
         const f3 corner = mk3((k & 4) ? c.hi[0] : c.lo[0], (k & 2) ? c.hi[1] : c.lo[1], (k & 1) ? c.hi[2] : c.lo[2]);
-        const f3 dir = normalize(corner - p);
+        const f3 dir = normalize(corner - spPos);
         minDot = __builtin_fminf(minDot, gclamp(dot(axis, dir), -1.0f, 1.0f));
     }
-    return acos_f(minDot);
-}
-RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
-    const float theta_u = cone_theta_to_box(c, spPos);
-    f3 dir = spPos - mk3(c.centroid[0], c.centroid[1], c.centroid[2]);
-    const float d2 = __builtin_fmaxf(dot(dir, dir), 1e-12f);
-    dir = normalize(dir);
+    const float theta_u = acos_f(minDot);
+    const float d2 = __builtin_fmaxf(dd, 1e-12f);               // == dot(p - centroid, p - centroid)
+    const f3 dir = -axis;                                       // == normalize(p - centroid)
     const float dotVal = gclamp(dot(mk3(c.axis[0], c.axis[1], c.axis[2]), dir), -1.0f, 1.0f);
     const float theta = acos_f(dotVal);
     const float angleTerm = gclamp((theta - c.theta_o) - theta_u, 0.0f, c.theta_e);

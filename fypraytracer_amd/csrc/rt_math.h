@@ -60,28 +60,30 @@ RT_DEV m4 mul(const m4& a, const m4& b) {
 constexpr float kPi = 3.1415926535f;   // MathUtils.cuh:17
 
 // ------------------------------------------------------------------ transcendentals (binary64 kernels)
+// The polynomial coefficients live in constant memory: the compiler fetches them with scalar loads into SGPR pairs and feeds
+// them to v_fma_f64 as the scalar operand.  Written as literals they were hoisted out of the light-tree loops into ~45 VGPRs
+// (a 64-bit literal cannot be an inline operand), which cost the shading kernels one to two waves of occupancy.
+__constant__ double kSinPoly[6] = {-1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
+__constant__ double kCosPoly[7] = {1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5};
+__constant__ double kAsinPoly[11] = {0x1.c88ae5be4eda1p-6, -0x1.bf334244335c0p-8, 0x1.fa509e4630b10p-7, 0x1.510d3e4b404ecp-7, 0x1.cf67181b8b240p-7,
+                                     0x1.1c0cd5e2c5a38p-6, 0x1.6e8f421105f62p-6, 0x1.f1c6fee482ca3p-6, 0x1.6db6dbab38ae8p-5, 0x1.33333333018c8p-4,
+                                     0x1.55555555555bcp-3};
+__constant__ double kPiSplit[4] = {0x1.45f306dc9c883p-1, 0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54, 0x1.921fb54442d18p+1};   // 2/pi, pi/2 hi, pi/2 lo, pi
 RT_DEV void sincos_f(float xf, float& s_out, float& c_out) {
     // valid for xf in [0, 2*pi + eps] (2*pi*u) and small positive angles; Cody–Waite by pi/2
     const double x = (double)xf;
-    const double kd = __builtin_rint(x * 0x1.45f306dc9c883p-1);
+    const double kd = __builtin_rint(x * kPiSplit[0]);
     const int k = (int)kd;
-    double r = __builtin_fma(-kd, 0x1.921fb54442d18p+0, x);
-    r = __builtin_fma(-kd, 0x1.1a62633145c07p-54, r);
+    double r = __builtin_fma(-kd, kPiSplit[1], x);
+    r = __builtin_fma(-kd, kPiSplit[2], r);
     const double z = r * r;
-    double sp = -1.0 / 6227020800.0;
-    sp = __builtin_fma(sp, z, 1.0 / 39916800.0);
-    sp = __builtin_fma(sp, z, -1.0 / 362880.0);
-    sp = __builtin_fma(sp, z, 1.0 / 5040.0);
-    sp = __builtin_fma(sp, z, -1.0 / 120.0);
-    sp = __builtin_fma(sp, z, 1.0 / 6.0);
+    double sp = kSinPoly[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) sp = __builtin_fma(sp, z, kSinPoly[i]);
     const double sr = __builtin_fma(-(r * z), sp, r);
-    double cp = 1.0 / 87178291200.0;
-    cp = __builtin_fma(cp, z, -1.0 / 479001600.0);
-    cp = __builtin_fma(cp, z, 1.0 / 3628800.0);
-    cp = __builtin_fma(cp, z, -1.0 / 40320.0);
-    cp = __builtin_fma(cp, z, 1.0 / 720.0);
-    cp = __builtin_fma(cp, z, -1.0 / 24.0);
-    cp = __builtin_fma(cp, z, 0.5);
+    double cp = kCosPoly[0];
+#pragma unroll
+    for (int i = 1; i < 7; ++i) cp = __builtin_fma(cp, z, kCosPoly[i]);
     const double cr = __builtin_fma(-z, cp, 1.0);
     const int q = k & 3;
     const double s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
@@ -91,32 +93,24 @@ RT_DEV void sincos_f(float xf, float& s_out, float& c_out) {
 RT_DEV float cos_f(float x) { float s, c; sincos_f(x, s, c); return c; }
 RT_DEV float pow5_f(float x) { const double d = (double)x; const double d2 = d * d; return (float)((d2 * d2) * d); }   // glm::pow(x, 5.0f)
 RT_DEV double asin_kernel(double z) {   // (asin(sqrt z)/sqrt z - 1)/z on [0, 0.25]; tools/gen_detmath_coeffs.py
-    double p = 0x1.c88ae5be4eda1p-6;
-    p = __builtin_fma(p, z, -0x1.bf334244335c0p-8);
-    p = __builtin_fma(p, z, 0x1.fa509e4630b10p-7);
-    p = __builtin_fma(p, z, 0x1.510d3e4b404ecp-7);
-    p = __builtin_fma(p, z, 0x1.cf67181b8b240p-7);
-    p = __builtin_fma(p, z, 0x1.1c0cd5e2c5a38p-6);
-    p = __builtin_fma(p, z, 0x1.6e8f421105f62p-6);
-    p = __builtin_fma(p, z, 0x1.f1c6fee482ca3p-6);
-    p = __builtin_fma(p, z, 0x1.6db6dbab38ae8p-5);
-    p = __builtin_fma(p, z, 0x1.33333333018c8p-4);
-    p = __builtin_fma(p, z, 0x1.55555555555bcp-3);
+    double p = kAsinPoly[0];
+#pragma unroll
+    for (int i = 1; i < 11; ++i) p = __builtin_fma(p, z, kAsinPoly[i]);
     return p;
 }
 RT_DEV float acos_f(float xf) {
+    // |x| <= 0.5: pi/2 - asin(x) with asin(x) = x + x*z*P(z), z = x*x;  else: 2*asin(sqrt z) with z = (1 - |x|)/2, reflected for x < 0.
+    // Both ranges share ONE evaluation of the polynomial (a wave whose lanes fall in both ranges would otherwise run it twice); the
+    // per-lane operations and their order are those of the two-branch form.
     const double x = (double)xf;
     const double ax = __builtin_fabs(x);
     if (!(ax <= 1.0)) return __builtin_nanf("");
-    if (ax <= 0.5) {
-        const double z = x * x;
-        const double as = __builtin_fma(x * z, asin_kernel(z), x);
-        return (float)(0x1.921fb54442d18p+0 - as);
-    }
-    const double z = (1.0 - ax) * 0.5;
-    const double s = __builtin_sqrt(z);
+    const bool small = ax <= 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    double s = x;
+    if (!small) s = __builtin_sqrt(z);
     const double as = __builtin_fma(s * z, asin_kernel(z), s);
-    return (float)(x > 0.0 ? 2.0 * as : 0x1.921fb54442d18p+1 - 2.0 * as);
+    return (float)(small ? kPiSplit[1] - as : (x > 0.0 ? 2.0 * as : kPiSplit[3] - 2.0 * as));
 }
 
 // ------------------------------------------------------------------ RNG (MathUtils.cuh:47-59)

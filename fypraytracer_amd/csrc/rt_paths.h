@@ -30,7 +30,8 @@ struct PathIO {
     float4* raysOut; uint32_t* countOut;                                      // rays of the next step
     float4* state; uint32_t stateStride;                                      // per-pixel path state, float4 units
     uint32_t iteration, raysPer;                                              // rays per entry (2 for NEE with more than one bounce)
-    uint32_t* part2List; uint32_t* part2Count;                                // ReSTIR GI: pixels that continue into Part 2
+    uint32_t* part2List; uint32_t* part2Count;                                // ReSTIR GI: pixels that continue into Part 2; NEE: the PICK list (counter = countOut)
+    uint32_t* misList; uint32_t* misCount;                                    // NEE: paths whose BRDF ray hit an emitter
 };
 
 struct RayRec { float4 q0, q1, q2; };
@@ -213,9 +214,32 @@ RT_DEV bool light_step(const DevScene& sc, const DevCamera& cam, const DevFrame&
 }
 
 // ============================================================ NEE + BRDF MIS (Renderer.cu:1411-1626): per bounce a shadow ray AND the bounce ray
-// state: S0 = throughput, seed | S1 = radiance, sample | bounce << 16 | S2 = pending direct contribution (added iff the light is visible), pdfBRDF
-RT_DEV bool nee_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& o0, RayRec& o1) {
-    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+// Three kernels per step, so that each light-tree descent runs on densely packed lanes and no kernel holds two of them:
+//   k_shade<T_NEE>  (nee_consume)  results of the previous step's rays: the prepared direct term if the light is visible; bounce ray ->
+//                   sky / emitter / surface.  A path that goes on is appended to the PICK list (ballot compaction) with its shading
+//                   point in the state record; a path whose BRDF ray hit an emitter to the MIS list (a few percent of the paths —
+//                   but nearly every wave holds one, and ComputeDirectEmitterPMF is a whole light-tree descent: inline it ran at
+//                   2-5 % lane utilisation in every wave); a path that ended otherwise starts its next sample or is finished.
+//   k_nee_mis       one thread per MIS-list path: MIS weight of the BRDF-sampled emitter hit (R.cu:1588-1612), then next sample
+//                   (-> PICK list) or the pixel's epilogue.
+//   k_nee_emit      one thread per PICK-list path: light pick (light-tree descent), light point, direct term + MIS weight, BRDF sample
+//                   -> shadow ray + bounce ray at the entry's own slot (every entry emits: no further compaction).
+// state: S0 = throughput, seed | S1 = radiance, sample | bounce << 16 | S2 = pending direct contribution, pdfBRDF
+//        S3 = shading point, u | S4 = shading normal, v | S5 = incoming direction, triangle
+// next sample of a path that ended (restart from the primary hit), or false when all samples are done
+RT_DEV bool nee_next_sample(const DevCamera& cam, const DevFrame& fr, const DevSettings& st, uint32_t i, int s, uint32_t& seed, float4* S, f3 radiance) {
+    if (!(s < (int)st.sampleCount && st.maxBounces > 0u)) return false;
+    seed += (uint32_t)((s + 1) * 31);
+    const Payload pp = fr.payload[i];
+    const f3 pd = ray_direction(cam, i % fr.W, i / fr.W);
+    S[0] = f3w(splat3(1.0f), seed); S[1] = f3w(radiance, (uint32_t)s); S[2] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    S[3] = make_float4(pp.px, pp.py, pp.pz, pp.u); S[4] = make_float4(pp.nx, pp.ny, pp.nz, pp.v); S[5] = f3w(pd, (uint32_t)pp.objectIndex);
+    return true;
+}
+// returns 1: goes on (PICK list), 2: BRDF ray hit an emitter (MIS list), 0: pixel finished
+RT_DEV int nee_consume(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, uint32_t& owner) {
+    const uint32_t i = owner_of(io, j);
+    owner = i;
     float4* S = io.state + (size_t)i * io.stateStride;
     const uint32_t maxBounces = st.maxBounces;
     uint32_t seed; int s = 0; uint32_t bounce = 0; f3 T = splat3(1.0f), radiance = splat3(0.0f), rd = splat3(0.0f); float pdfBRDF = 1.0f;
@@ -229,7 +253,7 @@ RT_DEV bool nee_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         const float4* R = io.raysIn + (size_t)j * io.raysPer * 3;
         const uint32_t lightTri = (uint32_t)__float_as_int(R[1].w);
         const float4 sh = io.hitsIn[(size_t)j * io.raysPer];
-        if (sh.x > 0.0f && (uint32_t)__float_as_int(sh.w) == lightTri) radiance = radiance + xyz(s2);      // the direct term prepared by the previous step
+        if (sh.x > 0.0f && (uint32_t)__float_as_int(sh.w) == lightTri) radiance = radiance + xyz(s2);      // the direct term prepared by k_nee_emit
         if (maxBounces != 1u) {
             const f3 ro = xyz(R[3]); rd = xyz(R[4]);
             const Hit h = load_hit(io.hitsIn, j * 2u + 1u);
@@ -237,18 +261,10 @@ RT_DEV bool nee_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             else {
                 hit = make_hit(sc, ro, rd, h);
                 const Mat em = load_mat(sc, tri_material(sc, hit.objectIndex));
-                if (length(emission(em)) > 0.0f) {
-                    const TriGeom eg = load_tri(sc, (uint32_t)hit.objectIndex);
-                    const f3 lp2 = tri_random_point(eg, seed);
-                    f3 ld2 = lp2 - pos3(hit);
-                    const float dist2 = length(ld2);
-                    ld2 = ld2 / dist2;
-                    const float cy = gmax(dot(-ld2, tri_normal(eg)), 1e-12f);
-                    const float triAreaPDF = 1.0f / tri_area(eg);
-                    const float lsa = (triAreaPDF * (dist2 * dist2)) / cy;
-                    const float pdfDirect = direct_emitter_pmf(sc, pos3(hit), (uint32_t)hit.objectIndex) * lsa;
-                    const float wB = pdfBRDF / gmax(pdfBRDF + pdfDirect, 1e-12f);
-                    radiance = radiance + (wB * T) * emission(em);
+                if (length(emission(em)) > 0.0f) {                         // -> k_nee_mis (with the radiance so far and the hit point)
+                    S[0] = f3w(T, seed); S[1] = f3w(radiance, (uint32_t)s | (bounce << 16)); S[2] = make_float4(0.0f, 0.0f, 0.0f, pdfBRDF);
+                    S[3] = make_float4(hit.px, hit.py, hit.pz, 0.0f); S[5] = f3w(rd, (uint32_t)hit.objectIndex);
+                    return 2;
                 } else {
                     ++bounce;
                     open = bounce < maxBounces;
@@ -257,47 +273,99 @@ RT_DEV bool nee_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         }
         if (!open) ++s;
     }
-    if (!open && s < (int)st.sampleCount && maxBounces > 0u) {            // next sample: restart from the primary hit
-        seed += (uint32_t)((s + 1) * 31);
-        T = splat3(1.0f); rd = ray_direction(cam, x, y); hit = fr.payload[i]; pdfBRDF = 1.0f; bounce = 0; open = true;
+    if (open) {
+        S[0] = f3w(T, seed); S[1] = f3w(radiance, (uint32_t)s | (bounce << 16)); S[2] = make_float4(0.0f, 0.0f, 0.0f, pdfBRDF);
+        S[3] = make_float4(hit.px, hit.py, hit.pz, hit.u); S[4] = make_float4(hit.nx, hit.ny, hit.nz, hit.v); S[5] = f3w(rd, (uint32_t)hit.objectIndex);
+        return 1;
     }
-    if (open) {                                                            // top of the bounce loop (R.cu:1452-1570)
-        const Mat mat = load_mat(sc, tri_material(sc, hit.objectIndex));
-        const f3 albedo = sample_albedo(sc, mat, hit.u, hit.v);
-        const PickedLight pl = pick_light(sc, pos3(hit), seed);
+    if (nee_next_sample(cam, fr, st, i, s, seed, S, radiance)) return 1;
+    epilogue(fr, i, rgb1(radiance / (float)st.sampleCount));
+    return 0;
+}
+
+// MIS weight of a BRDF-sampled emitter hit (R.cu:1588-1612) for the paths nee_consume listed; the sample ends with it
+__global__ __launch_bounds__(kBlock) void k_nee_mis(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, const uint32_t* misList, const uint32_t* misCount,
+                                                    float4* state, uint32_t stateStride, uint32_t* pickList, uint32_t* pickCount) {
+    const uint32_t n = *misCount;
+    for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < n; base += gridDim.x * (uint32_t)kBlock) {
+        const uint32_t j = base + threadIdx.x;
+        bool live = false; uint32_t i = 0;
+        if (j < n) {
+            i = misList[j];
+            float4* S = state + (size_t)i * stateStride;
+            const float4 s0 = S[0], s1 = S[1], s3 = S[3], s5 = S[5];
+            const f3 T = xyz(s0); uint32_t seed = (uint32_t)__float_as_int(s0.w); f3 radiance = xyz(s1);
+            int s = (int)((uint32_t)__float_as_int(s1.w) & 0xFFFFu);
+            const float pdfBRDF = S[2].w;
+            const f3 hpos = xyz(s3);
+            const uint32_t tri = (uint32_t)__float_as_int(s5.w);
+            const Mat em = load_mat(sc, tri_material(sc, (int)tri));
+            const TriGeom eg = load_tri(sc, tri);
+            const f3 lp2 = tri_random_point(eg, seed);
+            f3 ld2 = lp2 - hpos;
+            const float dist2 = length(ld2);
+            ld2 = ld2 / dist2;
+            const float cy = gmax(dot(-ld2, tri_normal(eg)), 1e-12f);
+            const float triAreaPDF = 1.0f / tri_area(eg);
+            const float lsa = (triAreaPDF * (dist2 * dist2)) / cy;
+            const float pdfDirect = direct_emitter_pmf(sc, hpos, tri) * lsa;
+            const float wB = pdfBRDF / gmax(pdfBRDF + pdfDirect, 1e-12f);
+            radiance = radiance + (wB * T) * emission(em);
+            ++s;
+            live = nee_next_sample(cam, fr, st, i, s, seed, S, radiance);
+            if (!live) epilogue(fr, i, rgb1(radiance / (float)st.sampleCount));
+        }
+        const uint32_t slot = block_append(live, pickCount);
+        if (live) pickList[slot] = i;
+    }
+}
+
+// top of the bounce loop (R.cu:1452-1570) for the paths nee_consume listed
+__global__ __launch_bounds__(kBlock) void k_nee_emit(DevScene sc, DevSettings st, const uint32_t* pixelList, const uint32_t* count, float4* state, uint32_t stateStride,
+                                                     float4* raysOut, uint32_t raysPer) {
+    const uint32_t n = *count;
+    for (uint32_t j = blockIdx.x * (uint32_t)kBlock + threadIdx.x; j < n; j += gridDim.x * (uint32_t)kBlock) {
+        const uint32_t i = pixelList[j];
+        float4* S = state + (size_t)i * stateStride;
+        const float4 s0 = S[0], s3 = S[3], s4 = S[4], s5 = S[5];
+        f3 T = xyz(s0); uint32_t seed = (uint32_t)__float_as_int(s0.w);
+        const f3 hpos = xyz(s3), hnrm = xyz(s4), rd = xyz(s5);
+        const int hitTri = __float_as_int(s5.w);
+        const uint32_t maxBounces = st.maxBounces;
+        const PickedLight pl = pick_light(sc, hpos, seed);
+        const Mat mat = load_mat(sc, tri_material(sc, hitTri));
+        const f3 albedo = sample_albedo(sc, mat, s3.w, s4.w);
         const TriGeom g = load_tri(sc, pl.tri);
         const f3 lp = tri_random_point(g, seed);
-        f3 ld = lp - pos3(hit);
+        f3 ld = lp - hpos;
         const float dist = length(ld);
         ld = ld / dist;
         f3 C;
         {
-            const f3 brdf = eval_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
-            const float cx = gmax(dot(ld, nrm3(hit)), 0.0f);
+            const f3 brdf = eval_brdf(hnrm, -rd, ld, albedo, mat.metallic, mat.roughness);
+            const float cx = gmax(dot(ld, hnrm), 0.0f);
             const float cy = gmax(dot(-ld, tri_normal(g)), 1e-12f);
             const float triAreaPDF = 1.0f / tri_area(g);
             const float lsa = (triAreaPDF * (dist * dist)) / cy;
             const float pdfDirect = pl.pmf * lsa;
-            const float pdfB = pdf_brdf(nrm3(hit), -rd, ld, albedo, mat.metallic, mat.roughness);
+            const float pdfB = pdf_brdf(hnrm, -rd, ld, albedo, mat.metallic, mat.roughness);
             const f3 em = emission(load_mat(sc, g.mat));
             if (maxBounces == 1u) C = (((T * brdf) * cx) * em) / pdfDirect;
             else { const float wD = pdfDirect / gmax(pdfB + pdfDirect, 1e-12f); C = ((((wD * T) * brdf) * cx) * em) / pdfDirect; }
         }
-        const f3 origin = pos3(hit) + nrm3(hit) * 1e-12f;
-        o0 = ray_shadow(sc, origin, ld, i, pl.tri);
+        const f3 origin = hpos + hnrm * 1e-12f;
+        store_ray(raysOut, j * raysPer, ray_shadow(sc, origin, ld, i, pl.tri));
+        float pdfBRDF = S[2].w;
         if (maxBounces != 1u) {
-            const f3 nd = sample_brdf(nrm3(hit), -rd, albedo, mat.metallic, mat.roughness, seed, pdfBRDF);
+            const f3 nd = sample_brdf(hnrm, -rd, albedo, mat.metallic, mat.roughness, seed, pdfBRDF);
             pdfBRDF = gmax(pdfBRDF, 1e-12f);
-            const f3 brdf = eval_brdf(nrm3(hit), -rd, nd, albedo, mat.metallic, mat.roughness);
-            const float cosT = dot(nd, nrm3(hit));
+            const f3 brdf = eval_brdf(hnrm, -rd, nd, albedo, mat.metallic, mat.roughness);
+            const float cosT = dot(nd, hnrm);
             T = T * ((brdf * cosT) / pdfBRDF);
-            o1 = ray_closest(origin, nd, i);
+            store_ray(raysOut, j * 2u + 1u, ray_closest(origin, nd, i));
         }
-        S[0] = f3w(T, seed); S[1] = f3w(radiance, (uint32_t)s | (bounce << 16)); S[2] = f3f(C, pdfBRDF);
-        return true;
+        S[0] = f3w(T, seed); S[2] = f3f(C, pdfBRDF);
     }
-    epilogue(fr, i, rgb1(radiance / (float)st.sampleCount));
-    return false;
 }
 
 // ============================================================ ReSTIR GI Part 1 (Renderer.cu:2043-2293)
@@ -499,28 +567,35 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 }
 
 // ============================================================ the shade kernel: one thread per live path, grid-stride over the list
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES
+#endif
 template <int TECH>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, PathIO io) {
+__global__ __launch_bounds__(kBlock) RT_SHADE_WAVES void k_shade(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, PathIO io) {
     const uint32_t count = *io.countIn;
     for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < count; base += gridDim.x * (uint32_t)kBlock) {
         const uint32_t j = base + threadIdx.x;
         bool live = false, toPart2 = false;
-        RayRec r0, r1;
+        RayRec r0; uint32_t owner = 0;
         if (j < count) {
             if (TECH == T_LIGHT) live = light_step(sc, cam, fr, st, io, j, r0);
-            else if (TECH == T_NEE) live = nee_step(sc, cam, fr, st, io, j, r0, r1);
+            else if (TECH == T_NEE) { const int k = nee_consume(sc, cam, fr, st, io, j, owner); live = k == 1; toPart2 = k == 2; }
             else if (TECH == T_GI1) live = gi1_step(sc, cam, fr, st, io, j, r0, toPart2);
             else if (TECH == T_GI2) live = gi2_step(sc, cam, fr, st, io, j, r0);
             else live = path_step<(TECH <= T_BRDF ? TECH : T_BRUTE)>(sc, cam, fr, st, io, j, r0);
         }
         const uint32_t slot = block_append(live, io.countOut);
         if (live) {
-            store_ray(io.raysOut, slot * io.raysPer, r0);
-            if (TECH == T_NEE && io.raysPer == 2u) store_ray(io.raysOut, slot * 2u + 1u, r1);
+            if (TECH == T_NEE) io.part2List[slot] = owner;             // NEE: the rays are built by k_nee_emit from this list
+            else store_ray(io.raysOut, slot * io.raysPer, r0);
         }
         if (TECH == T_GI1) {
             const uint32_t slot2 = block_append(toPart2, io.part2Count);
             if (toPart2) io.part2List[slot2] = owner_of(io, j);
+        }
+        if (TECH == T_NEE) {                                           // BRDF rays that hit an emitter: MIS list (PathIO::misList)
+            const uint32_t slot2 = block_append(toPart2, io.misCount);
+            if (toPart2) io.misList[slot2] = owner;
         }
     }
 }

@@ -44,7 +44,14 @@ def run(name, sc, cam, W, H, st, frames=30, warm=5):
 
 
 def main():
-    hall = scenes.hall_scene()
+    only = set(sys.argv[1:])                      # e.g. "3 5": only these configs (for a profiler run)
+    global run
+    _run = run
+
+    def run(name, *a, **kw):
+        if not only or name.split()[0] in only:
+            _run(name, *a, **kw)
+    hall = scenes.hall_scene() if (not only or only & {"3", "4", "5"}) else None
     run("1 cornell 512x512 brute force 1spp 4 bounces", scenes.cornell_box(), scenes.cornell_camera(512, 512), 512, 512,
         capi.Settings(technique=capi.BRUTE_FORCE, light_bounces=4, sky_color=(0, 0, 0)))
     run("2 banana-standin 1080p cosine 4spp 2 bounces", scenes.banana_scene(), scenes.banana_camera(1920, 1080), 1920, 1080,
