@@ -31,7 +31,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL_NAMES = {7: ["k_di_part1", "k_di_part2_setup", "k_di_part2_trace"], 8: ["k_gi_part1", "k_gi_part2"]}
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 4 cycles at 2.4 GHz (MI355X_MICROARCH.md: chip parameters,
+# "vector-instruction ISSUE cost ... v_add_f32 / v_fma_f32 4")
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0          # 614.4 G wave-instructions / s
+KERNEL_NAMES = {7: ["k_di_part1", "k_di_part2_setup", "k_di_part2_trace"], 8: ["gi_part1_stages", "gi_part2_stages"]}
+
+
+def kernel_source_sha():
+    """Fingerprint of everything the device code is built from: counter summaries under profiles/ are stamped with it and are
+    only quoted while it still matches (a number measured on other kernels is not evidence for these)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted((ROOT / "fypraytracer_amd" / "csrc").glob("*")):
+        if f.suffix in (".h", ".hip", ".cpp", ".sh"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def streaming_bytes(tech, pixels_p1, finished_p1, pixels_p2, skipped_p2, neighbors):
@@ -146,8 +160,9 @@ def main():
         ctx.render_async(st)
         if G:
             image = images[k]
-            band = image[r0 * W: r0 * W + rows_per * W] if r1 - r0 == rows_per else torch.nn.functional.pad(image[r0 * W: r1 * W], (0, (rows_per - (r1 - r0)) * W))
             with torch.cuda.stream(ext_stream):       # RCCL waits for the frame's kernels, the next frame does not wait for RCCL
+                # (a short last band is padded HERE, on the stream the frame's kernels run on, so the copy is ordered after them)
+                band = image[r0 * W: r0 * W + rows_per * W] if r1 - r0 == rows_per else torch.nn.functional.pad(image[r0 * W: r1 * W], (0, (rows_per - (r1 - r0)) * W))
                 full = torch.empty(N * rows_per * W, dtype=band.dtype, device=band.device)
                 pending[k] = dist.all_gather_into_tensor(full, band, async_op=True)
                 gathered_box[0] = full
@@ -250,44 +265,68 @@ def main():
                 stream_b = [sb1, sb2]
         else:
             stream_b = [pixels_band * 48]
-        alg = []
+        # Algorithmic bytes per launch, priced AS THIS BUILD FETCHES THEM: 64 B per node visit (one 4-wide node record
+        # decides up to four child boxes), 48 B per triangle test (leaf record), 64 B per closest hit (shading record), plus the
+        # per-pixel streaming bytes.  SURVEY §8(d)'s formula (32 B per box test, 36 per triangle, 40 per hit) prices the reference's
+        # layout, not this one's, and is reported beside it.
+        alg, alg_survey = [], []
         for k in range(len(names)):
-            b = 32 * int(cs.part_box_tests[k]) + 36 * int(cs.part_tri_tests[k]) + 40 * int(cs.part_hits[k]) + stream_b[k]
-            alg.append(b)
-        dom = int(np.argmax(serial_ms[: len(names)] if serial_ms is not None else avg_ms))
-        achieved = alg[dom] / (avg_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "traffic.json"
+            closest_hits = int(cs.part_hits[k]) if not (tech == 7 and k == 2) else 0          # shadow rays fetch no shading record
+            alg.append(64 * int(cs.part_node_visits[k]) + 48 * int(cs.part_tri_tests[k]) + 64 * closest_hits + stream_b[k])
+            alg_survey.append(32 * int(cs.part_box_tests[k]) + 36 * int(cs.part_tri_tests[k]) + 40 * int(cs.part_hits[k]) + stream_b[k])
+        # durations of a kernel running ALONE (frames not pipelined): what a roofline fraction must be computed from — in the timed
+        # region neighbouring frames' launches overlap and share the chip
+        alone_ms = serial_ms[: len(names)] if serial_ms is not None else avg_ms
+        dom = int(np.argmax(alone_ms))
+        achieved = alg[dom] / (float(alone_ms[dom]) * 1e-3) / 1e9
+        # counters measured under rocprofv3 (own passes) for THIS kernel source: HBM bytes, VALU wave-instructions, lane utilisation
+        traffic, binding, counters_note = None, None, "no counter summary under profiles/"
+        tf = ROOT / "profiles" / "counters.json"
         if tf.exists():
             try:
                 tj = json.loads(tf.read_text())
-                key = f"{names[dom]}@{W}x{H}@{args.scene}"
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+                if tj.get("kernel_source_sha") != kernel_source_sha():
+                    counters_note = f"profiles/counters.json was measured on kernel source {tj.get('kernel_source_sha')}, this is {kernel_source_sha()}: stale, not quoted"
+                else:
+                    kc = tj["kernels"].get(f"{names[dom]}@{W}x{H}@{args.scene}")
+                    if kc:
+                        counters_note = f"profiles/{tj.get('round', '?')} (rocprofv3 --pmc, separate passes, frames not pipelined), commit {tj.get('commit', '?')}"
+                        traffic = kc.get("hbm_bytes_per_launch")
+                        if kc.get("valu_wave_instructions"):
+                            v = kc["valu_wave_instructions"] / (float(alone_ms[dom]) * 1e-3) / 1e9
+                            binding = {"bound": "valu", "achieved": round(v, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": round(v / VALU_PEAK_GINSTR, 4),
+                                       "valu_wave_instructions_per_launch": int(kc["valu_wave_instructions"]), "lane_utilisation": kc.get("lane_utilisation"),
+                                       "duration_ms": round(float(alone_ms[dom]), 4)}
+            except Exception as e:      # a damaged summary must not take the benchmark down
+                counters_note = f"profiles/counters.json unreadable: {e}"
         out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": int(alg[dom]), "avg_kernel_ms": round(float(avg_ms[dom]), 4),
-                           "kernels": {names[k]: {"avg_ms": round(float(avg_ms[k]), 4),
-                                                  **({"avg_ms_not_pipelined": round(float(serial_ms[k]), 4)} if serial_ms is not None else {}),
-                                                  "algorithmic_bytes": int(alg[k]),
-                                                  "rays": int(cs.part_rays[k]), "box_tests_per_ray": round(int(cs.part_box_tests[k]) / max(1, int(cs.part_rays[k])), 2),
+                           "hbm_frac_measured": (round(traffic / (float(alone_ms[dom]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                           "binding": binding, "counters": counters_note,
+                           "algorithmic_bytes_per_launch": int(alg[dom]), "duration_ms": round(float(alone_ms[dom]), 4),
+                           "duration": "stand-alone (frames not pipelined)" if serial_ms is not None else "timed region",
+                           "pricing": "as fetched: 64 B/node visit + 48 B/triangle test + 64 B/closest hit + streaming",
+                           "kernels": {names[k]: {"avg_ms_timed_region": round(float(avg_ms[k]), 4),
+                                                  **({"avg_ms_alone": round(float(serial_ms[k]), 4)} if serial_ms is not None else {}),
+                                                  "algorithmic_bytes": int(alg[k]), "algorithmic_bytes_survey_formula": int(alg_survey[k]),
+                                                  "rays": int(cs.part_rays[k]), "node_visits_per_ray": round(int(cs.part_node_visits[k]) / max(1, int(cs.part_rays[k])), 2),
+                                                  "box_tests_per_ray": round(int(cs.part_box_tests[k]) / max(1, int(cs.part_rays[k])), 2),
                                                   "tri_tests_per_ray": round(int(cs.part_tri_tests[k]) / max(1, int(cs.part_rays[k])), 2)}
                                        for k in range(len(names))}}
+        # whole frame: every kernel's algorithmic bytes over the frame time (must stay below the peak too)
+        out["roofline"]["frame_algorithmic_gbs"] = round(sum(alg) / (ms_per_step * 1e-3) / 1e9, 1)
         # sum of the per-launch hipEvent durations: with ReSTIR DI frames pipelined over two streams (Part 1 + setup of frame
         # N+1 beside the trace kernel of frame N) the launches overlap, so this sum exceeds ms_per_step
         out["kernel_ms_sum_per_frame"] = round(float(avg_ms.sum()), 4)
         out["frames_pipelined"] = pipelined
-        if serial_ms is not None:
-            out["roofline"]["achieved_not_pipelined"] = round(alg[dom] / (float(serial_ms[dom]) * 1e-3) / 1e9, 2)
 
         # ---- CPU baseline leg: the oracle (function-for-function port, reference traversal), N = 1 only
         if N == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, str(ROOT / "tests"))
             from oraclelib import Oracle, lib as orc_lib
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this process may use
             orc_lib().orc_set_threads(cores)
+            cores = int(orc_lib().orc_max_threads())             # what OpenMP will actually run with
             orc = Oracle(sc, W, H)
             orc.set_camera(cam)
             stc = capi.Settings(technique=tech, light_bounces=st.light_bounces, sample_count=1, sky_color=(0.0, 0.0, 0.0),
@@ -300,13 +339,13 @@ def main():
             dt = time.perf_counter() - tc
             out["cpu_baseline"] = {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                                    "sample": f"{args.cpu_frames} full {W}x{H} frames of the same workload (frames 1-{args.cpu_frames}), "
-                                             f"reference-order TLAS/BLAS traversal, OpenMP rows, {dt:.1f} s",
+                                             f"reference-order TLAS/BLAS traversal, OpenMP over 64-pixel row segments (dynamic), {cores} threads, {dt:.1f} s",
                                    "ms_per_frame": round(dt / args.cpu_frames * 1e3, 1)}
             orc.close()
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if N > 1:
+    if G:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
     // (R.cu:1650-1668) and becomes a task WITHOUT a ray that only carries its colour to the epilogue, so that Part 1 writes
     // neither image nor accumulation and every epilogue of the frame runs in one place (the trace kernel).
     bool live = false, noRay = false;
-    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = kNoRayTask, lightSlot = 0;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), Lvis = splat3(0.0f), Lsky = splat3(0.0f); uint32_t ti = kNoRayTask, lightSlot = 0; float tLight = -1.0f;
     Payload pp; Mat hm;
     if (inside) {
         pp = fr.payload[i];
@@ -94,6 +94,9 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         if (length(lem) > 0.0f) { Lvis = T * lem; Lvis = Lvis * R.W; }                         // R.cu:2018-2027
         Lsky = T * st.sky;                                                                     // R.cu:2028-2031
         ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
+        // the shadow ray's distance to its own light triangle (trace_shadow's first step), computed HERE at full lane utilisation so that
+        // a refill of the persistent trace kernel is two loads and three reciprocals (<= 0: the ray misses its light -> closest-hit fallback)
+        tLight = light_tri_distance(sc, ti, ro, rd);
         fr.depth[i] = pp.hitDistance;
         { f2 on; on.x = own.nx; on.y = own.ny; store_rec(fr.dprevWrite + i, pp.hitDistance, on, R); }
     }
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
     }
     if (queued) {
         float4* t = q.tasks + (size_t)slot * 4;
-        t[0] = make_float4(ro.x, ro.y, ro.z, __int_as_float((int)i));
+        t[0] = make_float4(ro.x, ro.y, ro.z, tLight);
         t[1] = make_float4(rd.x, rd.y, rd.z, __int_as_float((int)ti));
-        t[2] = make_float4(Lvis.x, Lvis.y, Lvis.z, 0.0f);
-        t[3] = make_float4(Lsky.x, Lsky.y, Lsky.z, 0.0f);
+        t[2] = make_float4(Lvis.x, Lvis.y, Lvis.z, __int_as_float((int)i));      // the pixel travels with both candidate radiances:
+        t[3] = make_float4(Lsky.x, Lsky.y, Lsky.z, __int_as_float((int)i));      // the epilogue loads exactly one of them
     }
 }
 
@@ -183,8 +186,9 @@ struct LaneRay {
 RT_DEV void lane_push(int32_t* lds, int& top, int32_t v) { lds[top * kBlock] = v; ++top; }
 RT_DEV int32_t lane_pop(int32_t* lds, int& top) { --top; return lds[top * kBlock]; }
 
-// register budget of the persistent trace kernels: 6 waves per SIMD (80 VGPRs) — with the 22 KB LDS stack of the bench tree 6 workgroups
-// fit a CU, and each resident workgroup more buys 4-5 % (profiles/README.md); the compiler's own allocation lands a few registers above
+// register budget of the persistent trace kernels: 6 waves per SIMD (80 VGPRs); left alone the compiler lands a few registers above that
+// boundary and loses a resident workgroup per CU.  (The ReSTIR DI kernel also fits 72 VGPRs = 7 waves without a spill, and the 22 KB LDS
+// stack of the bench tree lets a CU hold 7 workgroups — measured slower, 0.458 vs 0.438 ms: profiles/README.md r02.)
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES __attribute__((amdgpu_waves_per_eu(6)))
 #endif
@@ -220,10 +224,9 @@ RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const Sh
             // finished lanes run the fused epilogue together (accumulate, tonemap, pack) — batched here so that it
             // executes once per >= kRefillLanes rays instead of once per finished ray
             if (pending) {
-                const float4* t = q.tasks + (size_t)r.task * 4;
-                const uint32_t pixel = (uint32_t)__float_as_int(t[0].w);
-                f3 radiance = splat3(0.0f);
-                if (outcome != 0u) { const float4 L = t[outcome == 1u ? 2 : 3]; radiance = mk3(L.x, L.y, L.z); }
+                const float4 L = q.tasks[(size_t)r.task * 4 + (outcome == 2u ? 3 : 2)];
+                const uint32_t pixel = (uint32_t)__float_as_int(L.w);
+                const f3 radiance = (outcome != 0u) ? mk3(L.x, L.y, L.z) : splat3(0.0f);
                 epilogue(fr, pixel, rgb1(radiance)); pending = false;
             }
         }
@@ -253,22 +256,7 @@ RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const Sh
                 if (r.lightTri == kNoRayTask) { pending = true; outcome = 1u; }          // a finished pixel: straight to the epilogue with its colour (t[2])
                 else {
                 r.pk = make_raypk(r.o, safe_inv(r.d.x), safe_inv(r.d.y), safe_inv(r.d.z));
-                // light triangle first (same Möller–Trumbore as trace_shadow)
-                float tL = -1.0f;
-                {
-                    const float4* p = sc.triPos + (size_t)r.lightTri * 3;
-                    const float4 a = p[0], b = p[1], c = p[2];
-                    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z) - v0, e2 = mk3(c.x, c.y, c.z) - v0;
-                    const f3 hh = cross(r.d, e2);
-                    const float det = dot(e1, hh), f = 1.0f / det;
-                    const f3 s = r.o - v0;
-                    const float u = f * dot(s, hh);
-                    if (!(u < 0.0f || u > 1.0f)) {
-                        const f3 qq = cross(s, e1);
-                        const float v = f * dot(r.d, qq);
-                        if (!(v < 0.0f || (u + v) > 1.0f)) { const float tt = f * dot(e2, qq); if (tt > 0.0001f) tL = tt; }
-                    }
-                }
+                const float tL = t0.w;                                  // distance to the light triangle, from the setup kernel
                 r.closestMode = !(tL > 0.0f);
                 r.tL = r.closestMode ? 3.402823466e+38f : tL;
                 r.cut = r.tL * 1.000001f;

@@ -1,67 +1,89 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output of a profiled bench run (gpurun_out/<prefix>_{stats,FETCH_SI,WRITE_SI,TCC_HIT_}) into the
-tracked summaries under profiles/<round>/ and profiles/traffic.json.
-  usage: summarize_profile.py <prefix e.g. prof_r01d> <round dir e.g. r01> <bench json under rocprof>"""
+"""Turn the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/<prefix>_*) into the tracked summaries under
+profiles/<round>/ and profiles/counters.json (what bench.py quotes: HBM bytes, VALU wave-instructions and lane utilisation per
+launch — stamped with the kernel-source fingerprint and the commit they were measured on).
+  usage: summarize_profile.py <prefix, e.g. prof_r02> <round dir, e.g. r02>"""
 import collections
 import csv
 import glob
 import json
 import shutil
 import statistics
+import subprocess
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def kname(s):
+    return s.split("(")[0].replace("void ", "").replace("rt::", "").replace("<false>", "").strip()
 
 
 def main():
-    prefix, rnd, bench_json = sys.argv[1], sys.argv[2], sys.argv[3]
+    from bench import kernel_source_sha
+    prefix, rnd = sys.argv[1], sys.argv[2]
     out_dir = ROOT / "profiles" / rnd
     out_dir.mkdir(parents=True, exist_ok=True)
     g = ROOT / "gpurun_out"
     tag = "restir_di_1080p_hall1M"
-    shutil.copy(glob.glob(str(g / f"{prefix}_stats/runc/*_kernel_stats.csv"))[0], out_dir / f"{tag}_kernel_stats.csv")
-    shutil.copy(g / bench_json, out_dir / f"{tag}_bench_under_rocprof.json")
-    bench = json.loads((g / bench_json).read_text())
+    shutil.copy(glob.glob(str(g / f"{prefix}_stats/**/*_kernel_stats.csv"), recursive=True)[0], out_dir / f"{tag}_kernel_stats.csv")
+    shutil.copy(g / f"{prefix}_bench.json", out_dir / f"{tag}_bench_under_rocprof.json")
+    bench = json.loads((g / f"{prefix}_bench.json").read_text())
     # timed-region means from the kernel trace of the --stats run
     d = {}
-    for r in csv.DictReader(open(glob.glob(str(g / f"{prefix}_stats/runc/*_kernel_trace.csv"))[0])):
-        if r["Kernel_Name"].startswith("rt::k_"):
-            d.setdefault(r["Kernel_Name"].split("(")[0].replace("rt::", ""), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for r in csv.DictReader(open(glob.glob(str(g / f"{prefix}_stats/**/*_kernel_trace.csv"), recursive=True)[0])):
+        if "rt::k_" in r["Kernel_Name"]:
+            d.setdefault(kname(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     timed = {}
     w, k = bench["warmup"], bench["steps"]
     for name, v in d.items():
         t = v[w:w + k]
         if not t:
             continue
-        timed[name] = {"dispatches_total": len(v), "all_mean_us": round(statistics.mean(v) / 1e3, 2), "all_median_us": round(statistics.median(v) / 1e3, 2),
-                       "timed_region_dispatches": len(t), "timed_region_mean_us": round(statistics.mean(t) / 1e3, 2),
-                       "bench_hipEvent_avg_us_same_run": round(bench["roofline"]["kernels"].get(name, {}).get("avg_ms", float("nan")) * 1e3, 2)}
+        timed[name] = {"dispatches_total": len(v), "timed_region_dispatches": len(t), "timed_region_mean_us": round(statistics.mean(t) / 1e3, 2),
+                       "bench_hipEvent_avg_us_same_run": round(bench["roofline"]["kernels"].get(name, {}).get("avg_ms_timed_region", float("nan")) * 1e3, 2),
+                       "alone_mean_us_same_run (bench: frames not pipelined)": round(bench["roofline"]["kernels"].get(name, {}).get("avg_ms_alone", float("nan")) * 1e3, 2)}
     (out_dir / f"{tag}_timed_region.json").write_text(json.dumps(timed, indent=1))
-    # PMC passes
+    # PMC passes: mean per dispatch over the steady-state frames
     out = {}
-    for t in ("FETCH_SI", "WRITE_SI", "TCC_HIT_"):
-        f = glob.glob(str(g / f"{prefix}_{t}/runc/*_counter_collection.csv"))[0]
+    for f in glob.glob(str(g / f"{prefix}_*/**/*_counter_collection.csv"), recursive=True):
         agg, meta = collections.defaultdict(list), {}
         for r in csv.DictReader(open(f)):
-            if not r["Kernel_Name"].startswith("rt::k_") or "build_light" in r["Kernel_Name"]:
+            if "rt::k_" not in r["Kernel_Name"] or "build_light" in r["Kernel_Name"] or "<true>" in r["Kernel_Name"]:
                 continue
-            kn = r["Kernel_Name"].split("(")[0].replace("rt::", "")
+            kn = kname(r["Kernel_Name"])
             agg[(kn, r["Counter_Name"])].append(float(r["Counter_Value"]))
-            meta[kn] = {c: int(r[c]) for c in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+            meta[kn] = {"arch_vgpr_count_reported (allocation granules, not the compiler's count: see tools/kernel_resources.py)": int(r["VGPR_Count"]),
+                        "lds_block_size_reported (static LDS only; the traversal stack is dynamic LDS sized at launch)": int(r["LDS_Block_Size"]),
+                        "scratch_size": int(r["Scratch_Size"]), "grid_size": int(r["Grid_Size"]), "workgroup_size": int(r["Workgroup_Size"])}
         for (kn, c), v in agg.items():
-            v = v[2:-1] if len(v) > 4 else v          # drop warm-up and the instrumented frame
+            v = v[2:] if len(v) > 4 else v            # drop the warm-up frames
             out.setdefault(kn, {"dispatch": meta[kn]})[c] = {"mean_per_dispatch": sum(v) / len(v), "n": len(v)}
+    kernels = {}
     for kn, x in out.items():
-        x["hbm_read_bytes_corrected"] = x["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2      # MI355X_MICROARCH.md §HBM: x2 for 16-B/lane reads
-        x["hbm_write_bytes"] = x["WRITE_SIZE"]["mean_per_dispatch"] * 1024
-        x["hbm_bytes_per_launch"] = x["hbm_read_bytes_corrected"] + x["hbm_write_bytes"]
-        x["l2_hit_rate"] = x["TCC_HIT_sum"]["mean_per_dispatch"] / (x["TCC_HIT_sum"]["mean_per_dispatch"] + x["TCC_MISS_sum"]["mean_per_dispatch"])
+        m = lambda c: x[c]["mean_per_dispatch"] if c in x else None   # noqa: E731
+        y = {}
+        if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
+            x["hbm_read_bytes_corrected"] = m("FETCH_SIZE") * 1024 * 2      # MI355X_MICROARCH.md §HBM: x2 for 16-B/lane reads on gfx950
+            x["hbm_write_bytes"] = m("WRITE_SIZE") * 1024
+            y["hbm_bytes_per_launch"] = int(x["hbm_read_bytes_corrected"] + x["hbm_write_bytes"])
+        if m("TCC_HIT_sum") is not None:
+            y["l2_hit_rate"] = round(m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum")), 4)
+        if m("SQ_INSTS_VALU") is not None:
+            y["valu_wave_instructions"] = int(m("SQ_INSTS_VALU"))
+        if m("SQ_THREAD_CYCLES_VALU") is not None and m("SQ_ACTIVE_INST_VALU"):
+            y["lane_utilisation"] = round(m("SQ_THREAD_CYCLES_VALU") / (64.0 * m("SQ_ACTIVE_INST_VALU")), 3)
+        if m("SQ_WAIT_ANY") is not None and m("SQ_WAVE_CYCLES"):
+            y["wait_any_over_wave_cycles"] = round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 3)
+        x["derived"] = y
+        kernels[f"{kn}@1920x1080@hall"] = y
     (out_dir / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1))
-    traffic = {f"{kn}@1920x1080@hall": {"hbm_bytes_per_launch": int(x["hbm_bytes_per_launch"]), "l2_hit_rate": round(x["l2_hit_rate"], 4),
-                                        "source": f"profiles/{rnd}/{tag}_pmc_summary.json"} for kn, x in out.items()}
-    (ROOT / "profiles" / "traffic.json").write_text(json.dumps(traffic, indent=1))
-    print(json.dumps({"timed": timed, "traffic": traffic}, indent=1))
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    counters = {"round": rnd, "commit": commit, "kernel_source_sha": kernel_source_sha(), "source": f"profiles/{rnd}/{tag}_pmc_summary.json", "kernels": kernels}
+    (ROOT / "profiles" / "counters.json").write_text(json.dumps(counters, indent=1))
+    print(json.dumps({"timed": timed, "counters": counters}, indent=1))
 
 
 if __name__ == "__main__":
