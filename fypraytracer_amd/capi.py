@@ -124,6 +124,9 @@ EXPORTED_SYMBOLS = [
     "fyprt_image_device_ptr", "fyprt_set_external_image", "fyprt_stream", "fyprt_read_buffer", "fyprt_frame_timings",
     "fyprt_reset_frame_index", "fyprt_frame_index", "fyprt_export_bvh", "fyprt_export_lighttrees", "fyprt_get_tuning", "fyprt_update_vertices",
     "fyprt_set_ray_counting", "fyprt_set_tuning", "fyprt_version",
+    "fyprt_group_create", "fyprt_group_destroy", "fyprt_group_set_rows", "fyprt_group_set_halo_mode", "fyprt_group_render", "fyprt_group_gather",
+    "fyprt_group_synchronize", "fyprt_comm_unique_id", "fyprt_comm_init_rank", "fyprt_comm_set_rows", "fyprt_comm_set_halo_mode", "fyprt_comm_render",
+    "fyprt_comm_gather", "fyprt_comm_destroy", "fyprt_render_part", "fyprt_balance_rows", "fyprt_last_frame_ms", "fyprt_halo_plan",
 ]
 
 
@@ -173,6 +176,26 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_set_ray_counting.argtypes = [vp, C.c_int]
     lib.fyprt_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     lib.fyprt_version.restype = C.c_char_p
+    lib.fyprt_group_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(u32), C.POINTER(vp)]
+    lib.fyprt_group_destroy.argtypes = [vp]
+    lib.fyprt_group_destroy.restype = None
+    lib.fyprt_group_set_rows.argtypes = [vp, C.POINTER(u32)]
+    lib.fyprt_group_set_halo_mode.argtypes = [vp, C.c_int]
+    lib.fyprt_group_render.argtypes = [vp, C.POINTER(Settings)]
+    lib.fyprt_group_gather.argtypes = [vp, C.c_int]
+    lib.fyprt_group_synchronize.argtypes = [vp]
+    lib.fyprt_comm_unique_id.argtypes = [vp]
+    lib.fyprt_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(u32)]
+    lib.fyprt_comm_set_rows.argtypes = [vp, C.POINTER(u32)]
+    lib.fyprt_comm_set_halo_mode.argtypes = [vp, C.c_int]
+    lib.fyprt_comm_render.argtypes = [vp, C.POINTER(Settings)]
+    lib.fyprt_comm_gather.argtypes = [vp, C.c_int]
+    lib.fyprt_comm_destroy.argtypes = [vp]
+    lib.fyprt_comm_destroy.restype = None
+    lib.fyprt_render_part.argtypes = [vp, C.POINTER(Settings), C.c_int]
+    lib.fyprt_balance_rows.argtypes = [C.POINTER(u32), C.POINTER(C.c_float), C.c_int, u32, u32, C.POINTER(u32)]
+    lib.fyprt_last_frame_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.fyprt_halo_plan.argtypes = [C.POINTER(u32), C.c_int, u32, u32, C.c_int, C.POINTER(u32), C.c_int]
     for f in EXPORTED_SYMBOLS:
         fn = getattr(lib, f)
         if fn.restype is C.c_int:
@@ -363,3 +386,67 @@ class Context:
         self._check(self.lib.fyprt_export_lighttrees(self.h, _ptr(tlas), C.byref(tc), C.byref(tr), _ptr(blas), C.byref(bt),
                                                      _ptr(first), _ptr(count), _ptr(root)))
         return {"tlas": tlas, "tlas_root": tr.value, "blas": blas, "blas_first": first, "blas_count": count, "blas_root": root}
+
+
+def _u32_array(values):
+    return (C.c_uint32 * len(values))(*[int(v) for v in values])
+
+
+class Group:
+    """Several contexts (one per GPU) of ONE process rendering one frame in row bands: fyprt_group_* (peer copies, no RCCL)."""
+
+    def __init__(self, contexts, row_bounds, halo_mode=0):
+        self.contexts, self.lib = list(contexts), contexts[0].lib
+        arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        h = C.c_void_p()
+        rc = self.lib.fyprt_group_create(arr, len(contexts), _u32_array(row_bounds), C.byref(h))
+        if rc != 0:
+            raise FyprtError(f"fyprt_group_create failed ({rc}): {self.lib.fyprt_last_error(contexts[0].h).decode()}")
+        self.h, self.row_bounds = h, list(row_bounds)
+        self.set_halo_mode(halo_mode)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FyprtError(f"fyprt error {rc}: " + " | ".join(self.lib.fyprt_last_error(c.h).decode() for c in self.contexts))
+
+    def set_halo_mode(self, mode):
+        self._check(self.lib.fyprt_group_set_halo_mode(self.h, mode))
+
+    def set_rows(self, row_bounds):
+        self._check(self.lib.fyprt_group_set_rows(self.h, _u32_array(row_bounds)))
+        self.row_bounds = list(row_bounds)
+
+    def render(self, settings):
+        self._check(self.lib.fyprt_group_render(self.h, C.byref(settings)))
+
+    def gather(self, root=0):
+        self._check(self.lib.fyprt_group_gather(self.h, root))
+
+    def synchronize(self):
+        self._check(self.lib.fyprt_group_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fyprt_group_destroy(self.h)
+            self.h = None
+
+
+def balance_rows(row_bounds, band_ms, min_rows=16, max_shift=1 << 30, lib=None):
+    """fyprt_balance_rows: cost-balanced band boundaries from the per-band frame times."""
+    lib = lib or load_library()
+    n = len(band_ms)
+    out = (C.c_uint32 * (n + 1))()
+    rc = lib.fyprt_balance_rows(_u32_array(row_bounds), (C.c_float * n)(*[float(x) for x in band_ms]), n, min_rows, max_shift, out)
+    if rc != 0:
+        raise FyprtError(f"fyprt_balance_rows failed ({rc})")
+    return list(out)
+
+
+def halo_plan(row_bounds, halo, height, wrap_row=True, lib=None):
+    """fyprt_halo_plan: [(receiver, owner, first row, end row), ...] of one halo exchange."""
+    lib = lib or load_library()
+    n = len(row_bounds) - 1
+    cnt = lib.fyprt_halo_plan(_u32_array(row_bounds), n, halo, height, 1 if wrap_row else 0, None, 0)
+    out = (C.c_uint32 * (4 * max(cnt, 1)))()
+    lib.fyprt_halo_plan(_u32_array(row_bounds), n, halo, height, 1 if wrap_row else 0, out, cnt)
+    return [tuple(out[4 * k: 4 * k + 4]) for k in range(cnt)]

@@ -44,7 +44,11 @@ void matmul_cm(const float* a, const float* b, float* out) {
 
 }  // namespace
 
+struct ncclUniqueIdBytes { char b[128]; };        // == ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
+
 struct fyprt_context {
+    // multi-process multi-GPU (fyprt_comm_*, fyprt_multi.h): RCCL communicator of the ranks that share the frame, every rank's band
+    void* comm = nullptr; int world = 1, rank = 0; std::vector<uint32_t> bounds; int commHaloMode = 0;
     int device = 0; hipStream_t stream = nullptr; std::string err; bool hostOnly = false;
     // ReSTIR DI frames are pipelined over two streams: Part 1 + Part-2 setup of frame N+1 (front stream) run beside the
     // persistent trace kernel of frame N (`stream`, on which every frame COMPLETES and which fyprt_stream() hands out)
@@ -52,6 +56,8 @@ struct fyprt_context {
     static constexpr int kRing = 128;          // frames whose per-launch hipEvents are kept (fyprt_frame_timings)
     hipEvent_t ring[kRing][5] = {}; int ringLaunches[kRing] = {}; unsigned long long frameSerial = 0; hipEvent_t* ev = nullptr;
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
+    bool haloExchange = false;   // halo rows of ReSTIR Part 1 come from the bands that own them (fyprt_multi.h) instead of being recomputed here
+    bool part1Pending = false;   // fyprt_render_part(1) was called, part 2 must follow
     uint32_t histDI[2] = {0, 0}, histGI[2] = {0, 0};   // rows [begin, end) whose ReSTIR DI / GI history this context holds (the band of the last such frame)
     bool haveScene = false, haveCamera = false, countRays = false;
     // per-pixel buffers
@@ -113,6 +119,8 @@ static int effective_stack_budget(const fyprt_context* c) {
 
 extern "C" {
 
+void fyprt_comm_destroy(fyprt_context* c);
+
 const char* fyprt_version(void) { return "fyprt 0.1.0 gfx950 (wave64, LDS traversal stack, fp-contract off)"; }
 
 int fyprt_create(int device_ordinal, fyprt_context** out) {
@@ -155,6 +163,7 @@ void fyprt_destroy(fyprt_context* c) {
     if (c->hostOnly) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    fyprt_comm_destroy(c);
     c->accum.release(); c->image.release(); c->payload.release(); c->depth.release(); c->normalA.release(); c->normalB.release();
     c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release(); c->drec.release(); c->dprevA.release(); c->dprevB.release();
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
@@ -558,12 +567,18 @@ static shade_kernel_t shade_kernel(int stage) {
     }
 }
 
-static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) {
+// phase: 0 = the whole frame; 1 = ReSTIR Part 1 only (nothing of the frame's bookkeeping advances); 2 = the rest of the frame that a
+// phase-1 call started.  The split exists for the halo EXCHANGE of a multi-GPU frame (fyprt_multi.h): Part 1 on every band, the
+// bands' Part-1 records of each other's halo rows copied across, Part 2 on every band.
+static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, int phase = 0) {
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context (device -1) cannot render");
     if (!c->haveScene || !c->haveCamera || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_render: resize, upload_scene and set_camera must precede render");
     if (c->dcam.W != c->W || c->dcam.H != c->H) return c->fail(FYPRT_ESTATE, "fyprt_render: camera viewport differs from the render size");
     const int tech = s->technique;
     if (tech < 0 || tech > 8) return c->fail(FYPRT_EINVAL, "fyprt_render: unknown technique");
+    if (phase != 0 && tech != FYPRT_RESTIR_DI && tech != FYPRT_RESTIR_GI) return c->fail(FYPRT_EINVAL, "fyprt_render_part: only the ReSTIR techniques have two parts");
+    if (phase == 2 && !c->part1Pending) return c->fail(FYPRT_ESTATE, "fyprt_render_part(2) without a preceding part 1");
+    if (phase != 2 && c->part1Pending) return c->fail(FYPRT_ESTATE, "a frame's part 1 is pending: call fyprt_render_part(ctx, settings, 2) first");
     if ((tech == FYPRT_LIGHT_SOURCE_SAMPLING || tech == FYPRT_NEE) && (c->dsc.emissiveCount == 0 || c->dsc.ltTlasCount == 0))
         return c->fail(FYPRT_ENOLIGHT, "fyprt_render: technique needs emissive triangles and a light tree");
     if (tech == FYPRT_RESTIR_DI && c->dsc.emissiveCount == 0) return c->fail(FYPRT_ENOLIGHT, "fyprt_render: ReSTIR DI needs emissive triangles");
@@ -598,15 +613,15 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     // `stream` alone, after everything before it.
     const int par = (int)(c->frameSerial & 1ull);
     const bool wavefront = tech == FYPRT_RESTIR_DI && c->tuning[1] == 1;
-    const bool overlap = wavefront && c->tuning[11] != 0 && !c->countRays;
+    const bool overlap = wavefront && c->tuning[11] != 0 && !c->countRays && phase == 0;
     hipStream_t fs = overlap ? c->front : c->stream;             // where Part 1 + setup go
     if (overlap) {
         HIPCHK(c, hipStreamWaitEvent(c->front, c->evDone[par], 0));                            // frame N-2 done: its queue is free
         if (!c->lastOverlapped) HIPCHK(c, hipStreamWaitEvent(c->front, c->evDone[par ^ 1], 0));   // frame N-1 ran on `stream` alone
     }
-    if (c->countRays) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 256, c->stream));
+    if (c->countRays && phase != 2) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 256, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51) — on `stream`, which owns it
-    if (c->frameIndex == 1) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
+    if (c->frameIndex == 1 && phase != 2) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
     fr.tileOrder = (uint32_t)c->tuning[0];
     fr.p1Mode = wavefront ? 1u : 0u;
@@ -619,7 +634,8 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
     const dim3 grid = gridFor(c->rowBegin, c->rowEnd);
     int ei = 0;
     c->ev = c->ring[c->frameSerial % fyprt_context::kRing];
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
+    if (phase == 2) ei = 1;
+    else if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
     int launches = 0;
     // ---- wavefront path engine (rt_paths.h): primary kernel, then per step one shade launch + one persistent trace launch
     struct StageRun { int stage; uint32_t steps, raysPer, stride; const uint32_t* pixelList; uint32_t* cnt; uint32_t* heads; uint32_t* part2List; uint32_t* part2Count; int counterPart; uint32_t* misCounts; };
@@ -684,14 +700,16 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
             break;
         }
         case FYPRT_RESTIR_DI: case FYPRT_RESTIR_GI: {
-            const uint32_t p1b = (c->rowBegin > c->halo) ? c->rowBegin - c->halo : 0u;
-            const uint32_t p1e = (c->rowEnd + c->halo < c->H) ? c->rowEnd + c->halo : c->H;
+            // halo rows: Part 1 recomputed on them (default), or — exchange mode — left to the band that owns them and copied in between the parts
+            const uint32_t p1halo = c->haloExchange ? 0u : c->halo;
+            const uint32_t p1b = (c->rowBegin > p1halo) ? c->rowBegin - p1halo : 0u;
+            const uint32_t p1e = (c->rowEnd + p1halo < c->H) ? c->rowEnd + p1halo : c->H;
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // Part 1 traces coherent primary rays only
             // The reference's spatial-neighbour coordinate is computed in unsigned arithmetic (R.cu:1916-1917): an offset
             // above the first row wraps and clamps to the LAST row.  A band that owns rows < radius therefore also needs
             // Part 1 of row H-1 (one extra row of recompute) to stay bit-identical to a single-GPU frame.  It rides in the same
             // launch as one more row of tiles (a separate one-row launch is all latency: ~0.09 ms on a 135-row band).
-            const bool extra = c->halo > 0 && c->rowBegin < c->halo && p1e < c->H;
+            const bool extra = p1halo > 0 && c->rowBegin < p1halo && p1e < c->H;
             const uint32_t extraRow = extra ? c->H - 1u : 0xFFFFFFFFu;
             const dim3 g1 = gridFor(p1b, extra ? p1e + 16u : p1e);
             if (tech == FYPRT_RESTIR_GI) {
@@ -701,22 +719,28 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
                 const size_t L1 = (size_t)steps1 + 2, L2 = (size_t)steps2 + 2;
                 { const int rc = ensure_paths(c, p1px, 1, 6, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
                 uint32_t* cnt1 = c->wfCounters.p; uint32_t* cnt2 = cnt1 + 2 * L1;      // cnt2[0] = length of the Part-2 list
-                HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
-                if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr};
-                { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
-                if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+                if (phase != 2) {
+                    HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
+                    if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
+                    else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
+                    StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr};
+                    { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
+                    if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
+                    if (phase == 1) { c->part1Pending = true; return c->hip(hipGetLastError(), "ReSTIR GI part 1"); }
+                }
                 StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr};
                 { const int rc = run_stage(r2); if (rc != FYPRT_OK) return rc; }
                 launches = 2;
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;
                 break;
             }
-            if (c->countRays) hipLaunchKernelGGL(k_di_part1<true>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
-            else hipLaunchKernelGGL(k_di_part1<false>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+            if (phase != 2) {
+                if (c->countRays) hipLaunchKernelGGL(k_di_part1<true>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+                else hipLaunchKernelGGL(k_di_part1<false>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
+                if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
+                if (phase == 1) { c->part1Pending = true; return c->hip(hipGetLastError(), "ReSTIR DI part 1"); }
+            }
             c->dsc.nodeQuorum = (uint32_t)c->tuning[6];   // shadow-ray kernels of ReSTIR DI Part 2: measured 0.85 -> 0.68 ms
-            if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
             if (c->countRays) c->dsc.rayCounter = c->rayCounter.p + 8;      // per-launch counters
             launches = 2;
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
@@ -759,6 +783,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed) 
         }
     }
     HIPCHK(c, hipGetLastError());
+    c->part1Pending = false;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
     HIPCHK(c, hipEventRecord(c->evDone[par], c->stream));                // the frame is complete (and its task queue free again)
     c->lastOverlapped = overlap;
@@ -929,5 +954,14 @@ int fyprt_set_tuning(fyprt_context* c, int key, int value) {
 }
 
 int fyprt_set_ray_counting(fyprt_context* c, int enabled) { if (!c) return FYPRT_EINVAL; c->countRays = enabled != 0; return FYPRT_OK; }
+
+// The two parts of a ReSTIR frame as separate calls, for a host that moves the halo rows between the bands itself (part 1, then its
+// own exchange of the buffers fyprt_multi.h lists, then part 2).  Asynchronous.
+int fyprt_render_part(fyprt_context* c, const fyprt_settings* s, int part) {
+    if (!c || !s || (part != 1 && part != 2)) return FYPRT_EINVAL;
+    return enqueue_frame(c, s, true, part);
+}
+
+#include "fyprt_multi.h"
 
 }  // extern "C"

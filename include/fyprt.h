@@ -275,6 +275,45 @@ int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
  * traversal must use too). */
 int fyprt_get_tuning(fyprt_context* ctx, int key, int* value);
 
+/* ================================================================================================= multi-GPU
+ * The reference renders on one GPU (Renderer.cu:13-284); there is no reference interface for this section.  It splits ONE
+ * Renderer::Render call over several GPUs by image rows: every GPU holds the whole scene and renders a band;
+ * reservoirs, G-buffers and accumulation stay on the GPU that owns the rows; the RGBA8 bands are gathered once per frame.
+ * `row_bounds` always has (number of bands + 1) entries: band k = rows [row_bounds[k], row_bounds[k+1]), row_bounds[0] = 0,
+ * the last entry = height.
+ * Halo mode (the `radius` rows either side of a band that ReSTIR Part 2's spatial reuse reads):
+ *   0 recompute: every band also runs Part 1 on its halo rows; frame 1 equals the single-GPU frame, later frames differ (unbiased)
+ *                near band borders because the halo rows have no temporal history;
+ *   1 exchange : the bands send each other the Part-1 records (and the temporal history) of those rows — a static-camera
+ *                sequence then equals the single-GPU sequence bit for bit on every frame, and Part 1 does no duplicate work. */
+typedef struct fyprt_group fyprt_group;
+/* --- one process, one context per GPU (a C++ host such as the reference's MainLayer): peer copies, no collective library */
+int fyprt_group_create(fyprt_context** contexts, int n, const uint32_t* row_bounds, fyprt_group** out);
+void fyprt_group_destroy(fyprt_group* group);                       /* the contexts stay alive */
+int fyprt_group_set_rows(fyprt_group* group, const uint32_t* row_bounds);
+int fyprt_group_set_halo_mode(fyprt_group* group, int mode);
+int fyprt_group_render(fyprt_group* group, const fyprt_settings* settings);   /* one frame on every band; asynchronous */
+int fyprt_group_gather(fyprt_group* group, int root);               /* all bands' RGBA8 rows into context `root`'s image; asynchronous */
+int fyprt_group_synchronize(fyprt_group* group);
+/* --- one process per GPU: RCCL over xGMI (librccl.so.1 is opened on first use).  Rank 0 calls fyprt_comm_unique_id and hands
+ *     the 128 bytes to the other ranks (any transport); every rank then calls fyprt_comm_init_rank on its resized context. */
+int fyprt_comm_unique_id(void* id128);
+int fyprt_comm_init_rank(fyprt_context* ctx, int world_size, int rank, const void* id128, const uint32_t* row_bounds);
+int fyprt_comm_set_rows(fyprt_context* ctx, const uint32_t* row_bounds);
+int fyprt_comm_set_halo_mode(fyprt_context* ctx, int mode);
+int fyprt_comm_render(fyprt_context* ctx, const fyprt_settings* settings);    /* this rank's band; collective (every rank calls it); asynchronous */
+int fyprt_comm_gather(fyprt_context* ctx, int root /* < 0: every rank gets the frame */);   /* grouped ncclBroadcast per band, in place */
+void fyprt_comm_destroy(fyprt_context* ctx);
+/* --- building blocks */
+/* The two parts of a ReSTIR frame as separate asynchronous calls, for a host with its own transport for the halo rows. */
+int fyprt_render_part(fyprt_context* ctx, const fyprt_settings* settings, int part /* 1 or 2 */);
+/* Cost-balanced bands: new boundaries from the milliseconds each band took (fyprt_last_frame_ms), at most `max_shift` rows per
+ * boundary and call, bands at least `min_rows` high.  Rows that change owner lose their temporal history. */
+int fyprt_balance_rows(const uint32_t* row_bounds, const float* band_ms, int n, uint32_t min_rows, uint32_t max_shift, uint32_t* new_bounds);
+int fyprt_last_frame_ms(fyprt_context* ctx, float* ms);
+/* The transfers of one halo exchange: (receiver, owner, first row, end row) per entry; returns the number of entries. */
+int fyprt_halo_plan(const uint32_t* row_bounds, int n, uint32_t halo, uint32_t height, int wrap_row, uint32_t* out4, int capacity);
+
 /* Library / build identification ("fyprt <version> gfx950 ..."). */
 const char* fyprt_version(void);
 

@@ -1,0 +1,151 @@
+"""Multi-GPU layer of the C ABI on real kernels (include/fyprt.h "multi-GPU"): several contexts of one process render one frame in
+row bands (fyprt_group_*).  The box has one GPU, so the contexts share it — the code path is the one an 8-GPU host runs, with
+hipMemcpyPeerAsync degenerating to a same-device copy.
+  * halo mode 1 (exchange of the Part-1 records + temporal history of the halo rows): a static-camera ReSTIR sequence is
+    bit-identical to the single-context sequence on EVERY frame, for uneven bands too;
+  * halo mode 0 (recompute): frame 1 identical, later frames differ only near the borders (tests/test_gpu_multiband.py states the bound);
+  * fyprt_group_gather assembles the frame on the root context; fyprt_balance_rows + fyprt_group_set_rows move the borders;
+  * fyprt_comm_* (RCCL) with a communicator of ONE rank: init / render / gather / destroy run through librccl (the multi-rank
+    exchange itself cannot run on a one-GPU box: RCCL refuses two ranks on one device)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import SCENES, bits_equal, settings_for
+from fypraytracer_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _contexts(n, sc, cam, W, H):
+    out = []
+    for _ in range(n):
+        c = capi.Context(0)
+        c.resize(W, H)
+        c.upload_scene(sc)
+        c.set_camera(cam)
+        out.append(c)
+    return out
+
+
+def _single(sc, cam, W, H, tech, frames):
+    ctx = _contexts(1, sc, cam, W, H)[0]
+    st = settings_for(tech)
+    outs = []
+    for f in range(frames):
+        st.rand_seed = f + 1
+        ctx.render(st)
+        outs.append(ctx.readback())
+    ctx.close()
+    return outs
+
+
+def _stitched(ctxs, bounds, H, W):
+    img = np.zeros((H, W), np.uint32)
+    acc = np.zeros((H, W, 4), np.float32)
+    for c, (b, e) in zip(ctxs, zip(bounds, bounds[1:])):
+        c.set_rows(b, e, 0)                                  # readback covers the band's rows
+        i, a = c.readback()
+        img[b:e], acc[b:e] = i[b:e], a[b:e]
+    return img, acc
+
+
+@pytest.mark.parametrize("tech", [capi.RESTIR_DI, capi.RESTIR_GI])
+@pytest.mark.parametrize("bounds", [[0, 96, 192], [0, 40, 70, 150, 192]])
+def test_halo_exchange_equals_single_gpu_on_every_frame(tech, bounds):
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 160, 192
+    cam = mk_cam(W, H)
+    frames = 4
+    ref = _single(sc, cam, W, H, tech, frames)
+    ctxs = _contexts(len(bounds) - 1, sc, cam, W, H)
+    grp = capi.Group(ctxs, bounds, halo_mode=1)
+    st = settings_for(tech)
+    for f in range(frames):
+        st.rand_seed = f + 1
+        grp.render(st)
+        grp.synchronize()
+        img, acc = _stitched(ctxs, bounds, H, W)
+        eq = bits_equal(acc, ref[f][1]).all(axis=-1)
+        assert eq.all(), f"frame {f + 1}: {(~eq).sum()} pixels differ (rows {sorted(set(np.argwhere(~eq)[:, 0].tolist()))[:8]})"
+        assert np.array_equal(img, ref[f][0])
+    grp.gather(0)
+    grp.synchronize()
+    ctxs[0].set_rows(0, H, 0)
+    full, _ = ctxs[0].readback(want_accum=False)
+    assert np.array_equal(full, ref[-1][0])                  # the gathered frame on the root context
+    grp.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_recompute_mode_and_other_techniques_through_the_group():
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 160, 192
+    cam = mk_cam(W, H)
+    bounds = [0, 64, 128, 192]
+    for tech, frames in ((capi.RESTIR_DI, 1), (capi.NEE, 2), (capi.COSINE_WEIGHTED_SAMPLING, 2)):
+        ref = _single(sc, cam, W, H, tech, frames)
+        ctxs = _contexts(3, sc, cam, W, H)
+        grp = capi.Group(ctxs, bounds, halo_mode=0)
+        st = settings_for(tech)
+        for f in range(frames):
+            st.rand_seed = f + 1
+            grp.render(st)
+        grp.synchronize()
+        img, acc = _stitched(ctxs, bounds, H, W)
+        assert np.array_equal(img, ref[-1][0]) and bits_equal(acc, ref[-1][1]).all(), tech
+        grp.close()
+        for c in ctxs:
+            c.close()
+
+
+def test_balanced_rows_move_the_borders_and_the_sequence_stays_exact():
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 160, 192
+    cam = mk_cam(W, H)
+    bounds = [0, 96, 192]
+    ctxs = _contexts(2, sc, cam, W, H)
+    grp = capi.Group(ctxs, bounds, halo_mode=1)
+    st = settings_for(capi.RESTIR_DI)
+    for f in range(6):
+        st.rand_seed = f + 1
+        grp.render(st)
+        grp.synchronize()
+        if f == 2:
+            new = capi.balance_rows(bounds, [2.0, 1.0], min_rows=16, max_shift=24)      # band 0 took twice as long: it shrinks
+            assert new[0] == 0 and new[2] == H and 72 <= new[1] < 96
+            grp.set_rows(new)
+            bounds = new
+    img, acc = _stitched(ctxs, bounds, H, W)
+    ref = _single(sc, cam, W, H, capi.RESTIR_DI, 6)[-1]
+    # the rows that changed owner took their accumulation and history along: still the single-GPU sequence, bit for bit
+    assert np.array_equal(img, ref[0]) and bits_equal(acc, ref[1]).all()
+    grp.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_rccl_communicator_of_one_rank():
+    mk_scene, mk_cam = SCENES["cornell"]
+    sc, W, H = mk_scene(), 96, 80
+    cam = mk_cam(W, H)
+    ctx = _contexts(1, sc, cam, W, H)[0]
+    lib = ctx.lib
+    uid = (C.c_char * 128)()
+    assert lib.fyprt_comm_unique_id(uid) == 0, lib.fyprt_last_error(None)
+    bounds = (C.c_uint32 * 2)(0, H)
+    ctx._check(lib.fyprt_comm_init_rank(ctx.h, 1, 0, uid, bounds))
+    ctx._check(lib.fyprt_comm_set_halo_mode(ctx.h, 1))
+    st = settings_for(capi.RESTIR_DI)
+    ref = _single(sc, cam, W, H, capi.RESTIR_DI, 2)[-1]
+    for f in range(2):
+        st.rand_seed = f + 1
+        ctx._check(lib.fyprt_comm_render(ctx.h, C.byref(st)))
+        ctx._check(lib.fyprt_comm_gather(ctx.h, -1))
+    ctx.synchronize()
+    img, acc = ctx.readback()
+    assert np.array_equal(img, ref[0]) and bits_equal(acc, ref[1]).all()
+    lib.fyprt_comm_destroy(ctx.h)
+    ctx.close()
