@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--rehearse-gather", action="store_true", help="N = 1 only: run the per-frame RCCL all-gather path with a one-rank group (checks RCCL beside the pipelined streams)")
     ap.add_argument("--set", nargs="*", default=[], metavar="KEY=VALUE", help="fyprt_set_tuning knobs (experiments)")
+    ap.add_argument("--transport", default="torch", choices=["torch", "cabi"],
+                    help="N > 1: 'torch' = torch.distributed all_gather_into_tensor of the bands (default; the path rehearsed with gloo on one GPU); "
+                         "'cabi' = the library's own RCCL layer (fyprt_comm_render / fyprt_comm_gather: grouped ncclBroadcast per band, in place)")
+    ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
+                    help="--transport cabi only: ReSTIR halo rows recomputed per band, or exchanged between the bands (ncclSend / ncclRecv)")
+    ap.add_argument("--dump-image", default=None, help="rank 0 writes the frame gathered by the last timed step to this .npy file (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +142,20 @@ def main():
     for kv in args.set:
         k, v = kv.split("=")
         ctx.set_tuning(int(k), int(v))
+    cabi = G and args.transport == "cabi"
+    if cabi:
+        # the library's own communicator: rank 0 makes the RCCL id, torch.distributed only carries its 128 bytes to the other ranks
+        import ctypes as C
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda" if args.backend == "nccl" else "cpu")
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            ctx._check(ctx.lib.fyprt_comm_unique_id(buf))
+            uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        uid_bytes = (C.c_char * 128).from_buffer_copy(bytes(uid.cpu().numpy().tobytes()))
+        bounds = (C.c_uint32 * (N + 1))(*([multigpu.band_rows(H, N, r)[0] for r in range(N)] + [H]))
+        ctx._check(ctx.lib.fyprt_comm_init_rank(ctx.h, N, rank, uid_bytes, bounds))
+        ctx._check(ctx.lib.fyprt_comm_set_halo_mode(ctx.h, 1 if args.halo == "exchange" else 0))
 
     # The image lives in torch tensors so the RCCL gather needs no copy.  Two buffers alternate per frame: the gather of
     # frame k (on RCCL's stream, ordered after frame k's kernels through the context stream) overlaps frame k+1's kernels.
@@ -157,6 +177,11 @@ def main():
                 pending[k].wait()
             pending[k] = None
         ctx.set_external_image(images[k].data_ptr())
+        if cabi:                                      # band + (halo exchange) + in-place grouped broadcast of every band, all on the context's stream
+            ctx._check(ctx.lib.fyprt_comm_render(ctx.h, C.byref(st)))
+            ctx._check(ctx.lib.fyprt_comm_gather(ctx.h, -1))
+            gathered_box[0] = images[k]
+            return
         ctx.render_async(st)
         if G:
             image = images[k]
@@ -185,6 +210,9 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    dumped_image = None
+    if args.dump_image and rank == 0:
+        dumped_image = (gathered_box[0][: H * W] if G else images[(frame_no[0] - 1) & 1]).cpu().numpy().view(np.uint32).reshape(H, W).copy()
     n_timed = min(args.steps, 128)
     for fb in range(n_timed):
         ms, _n = ctx.frame_timings(fb)
@@ -231,6 +259,9 @@ def main():
     else:
         total_rays = float(useful_rays)
 
+    if args.dump_image and rank == 0:
+        last = gathered_box[0][: H * W] if G else images[(frame_no[0] - 1) & 1]       # (taken before the untimed extra frames below render into the buffers)
+        np.save(args.dump_image, dumped_image if dumped_image is not None else last.cpu().numpy().view(np.uint32).reshape(H, W))
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps) / 1e6
 
@@ -241,7 +272,8 @@ def main():
         "config": {"workload": f"{workload}_{W}x{H}_{capi.TECHNIQUE_NAMES[tech]}_1spp", "triangles": int(len(sc.triangles)),
                    "meshes": len(sc.meshes), "emissive_triangles": int(len(sc.emissive_triangles)),
                    "rays_per_frame": int(total_rays), "temporal_reuse": True, "spatial_reuse": True,
-                   "parallelism": f"row-bands x{N}" + (f" + {halo}-row halo recompute + RCCL all-gather(RGBA8)" if N > 1 else ""),
+                   "parallelism": f"row-bands x{N}" + ((f" + {halo}-row halo {args.halo} + RCCL grouped broadcast per band (C ABI)" if args.transport == "cabi" else
+                                                         f" + {halo}-row halo recompute + RCCL all-gather(RGBA8)") if N > 1 else ""),
                    "bvh_build_s": round(build_s, 2)},
     }
 

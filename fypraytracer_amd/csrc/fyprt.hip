@@ -80,7 +80,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[13] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[14] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
@@ -701,7 +701,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
         }
         case FYPRT_RESTIR_DI: case FYPRT_RESTIR_GI: {
             // halo rows: Part 1 recomputed on them (default), or — exchange mode — left to the band that owns them and copied in between the parts
-            const uint32_t p1halo = c->haloExchange ? 0u : c->halo;
+            const uint32_t p1halo = (c->haloExchange || c->tuning[13]) ? 0u : c->halo;
             const uint32_t p1b = (c->rowBegin > p1halo) ? c->rowBegin - p1halo : 0u;
             const uint32_t p1e = (c->rowEnd + p1halo < c->H) ? c->rowEnd + p1halo : c->H;
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // Part 1 traces coherent primary rays only
@@ -772,8 +772,11 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
                     }
                     perCU = c->traceOcc;
                 }
-                if (c->countRays) hipLaunchKernelGGL(k_di_part2_trace<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, c->dsc, fr, q);
-                else hipLaunchKernelGGL(k_di_part2_trace<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, c->dsc, fr, q);
+                // persistent grid: as many workgroups as the chip holds — but not more than the band has tasks for (one lane per task): a narrow
+                // multi-GPU band would otherwise park idle workgroups on the LDS / wave slots the next frame's Part 1 is waiting for
+                const uint32_t traceGrid = std::max(8u, std::min((uint32_t)(c->numCUs * perCU), grid.x));
+                if (c->countRays) hipLaunchKernelGGL(k_di_part2_trace<true>, dim3(traceGrid), block, ldsBytes, c->stream, c->dsc, fr, q);
+                else hipLaunchKernelGGL(k_di_part2_trace<false>, dim3(traceGrid), block, ldsBytes, c->stream, c->dsc, fr, q);
                 launches = 3;
             }
             else if (c->countRays) hipLaunchKernelGGL(k_di_part2<true>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st);
@@ -936,17 +939,17 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 13) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 14) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 13) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 14) return FYPRT_EINVAL;
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
-    static const int lo[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[13] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1};
+    static const int lo[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int hi[14] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1, 1};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

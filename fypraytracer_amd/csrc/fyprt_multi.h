@@ -311,11 +311,31 @@ int fyprt_comm_init_rank(fyprt_context* c, int world, int rank, const void* id12
     c->rowBegin = row_bounds[rank]; c->rowEnd = row_bounds[rank + 1]; c->rowsSet = true;
     return FYPRT_OK;
 }
+// New band boundaries for every rank (collective: every rank calls it with the same table, between two frames).  Rows that change
+// owner take their accumulation and temporal history along (grouped ncclSend / ncclRecv), as fyprt_group_set_rows does with peer copies.
 int fyprt_comm_set_rows(fyprt_context* c, const uint32_t* row_bounds) {
     if (!c || !row_bounds || !c->comm) return FYPRT_EINVAL;
     if (row_bounds[0] != 0 || row_bounds[c->world] != c->H) return c->fail(FYPRT_EINVAL, "fyprt_comm_set_rows: the bands must partition rows 0..height");
     for (int i = 0; i < c->world; ++i) if (row_bounds[i] >= row_bounds[i + 1]) return c->fail(FYPRT_EINVAL, "fyprt_comm_set_rows: empty or unordered band");
+    HIPCHK(c, hipSetDevice(c->device));
+    XBuf bufs[4] = {{c->accum.p, sizeof(float4)}, {c->dprevFlip ? (void*)c->dprevB.p : (void*)c->dprevA.p, sizeof(DIRec)}, {c->giPrev.p, sizeof(GIRes)},
+                    {c->normalFlip ? (void*)c->normalB.p : (void*)c->normalA.p, sizeof(f2)}};
+    NCCLCHK(c, g_rccl.GroupStart());
+    for (int k = 0; k < c->world; ++k)
+        for (int j = 0; j < c->world; ++j) {
+            if (j == k) continue;
+            const uint32_t r0 = std::max(row_bounds[k], c->bounds[j]), r1 = std::min(row_bounds[k + 1], c->bounds[j + 1]);
+            if (r0 >= r1 || (c->rank != k && c->rank != j)) continue;       // rows [r0, r1): owned by j so far, by k from now on
+            for (const XBuf& b : bufs) {
+                const size_t off = (size_t)r0 * c->W * b.bytesPerPixel, bytes = (size_t)(r1 - r0) * c->W * b.bytesPerPixel;
+                if (c->rank == k) NCCLCHK(c, g_rccl.Recv((char*)b.p + off, bytes, kNcclChar, j, c->comm, c->stream));
+                else NCCLCHK(c, g_rccl.Send((const char*)b.p + off, bytes, kNcclChar, k, c->comm, c->stream));
+            }
+        }
+    NCCLCHK(c, g_rccl.GroupEnd());
     c->bounds.assign(row_bounds, row_bounds + c->world + 1);
+    c->rowBegin = c->bounds[c->rank]; c->rowEnd = c->bounds[c->rank + 1];
+    c->histDI[0] = c->histGI[0] = c->rowBegin; c->histDI[1] = c->histGI[1] = c->rowEnd;
     return FYPRT_OK;
 }
 int fyprt_comm_set_halo_mode(fyprt_context* c, int mode) { if (!c || mode < 0 || mode > 1) return FYPRT_EINVAL; c->commHaloMode = mode; return FYPRT_OK; }

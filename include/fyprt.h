@@ -269,7 +269,10 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 12: builder of the acceleration structure for the NEXT fyprt_upload_scene: 0 (default) host binned SAH + SAH-optimal
  *        collapse; 1 device LBVH (Morton sort, Karras radix tree, collapse, refit) — milliseconds instead of a fraction of a
  *        second for a million triangles, a slower tree to trace; falls back to the host builder if the tree gets deeper than
- *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties). */
+ *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties).
+ * key 13: MEASUREMENT ONLY (tools/band_rate.py): 1 = a lone context skips ReSTIR Part 1 on its halo rows as a band does in halo-exchange
+ *        mode, without anybody filling them — the cost of one band of an exchange-mode split; the image near the band border is not valid.
+ * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 12, 13: 0..1, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
  * traversal must use too). */

@@ -138,7 +138,7 @@ def test_light_sorted_tasks_with_pipelined_async_frames():
 
 def test_tuning_values_are_range_checked():
     ctx = capi.Context(0)
-    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 0), (-1, 0)):
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 0), (-1, 0)):
         with pytest.raises(capi.FyprtError):
             ctx.set_tuning(key, bad)
     ctx.set_tuning(5, 64)
