@@ -127,6 +127,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_group_create", "fyprt_group_destroy", "fyprt_group_set_rows", "fyprt_group_set_halo_mode", "fyprt_group_render", "fyprt_group_gather",
     "fyprt_group_synchronize", "fyprt_comm_unique_id", "fyprt_comm_init_rank", "fyprt_comm_set_rows", "fyprt_comm_set_halo_mode", "fyprt_comm_render",
     "fyprt_comm_gather", "fyprt_comm_destroy", "fyprt_render_part", "fyprt_balance_rows", "fyprt_last_frame_ms", "fyprt_halo_plan",
+    "fyprt_set_object_vertices", "fyprt_update_transforms", "fyprt_compare_image",
 ]
 
 
@@ -176,6 +177,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_set_ray_counting.argtypes = [vp, C.c_int]
     lib.fyprt_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     lib.fyprt_version.restype = C.c_char_p
+    lib.fyprt_set_object_vertices.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    lib.fyprt_update_transforms.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), u32]
+    lib.fyprt_compare_image.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fyprt_group_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(u32), C.POINTER(vp)]
     lib.fyprt_group_destroy.argtypes = [vp]
     lib.fyprt_group_destroy.restype = None
@@ -361,6 +365,25 @@ class Context:
         """Moved geometry, same topology: refit on the device (fyprt_update_vertices)."""
         v = np.ascontiguousarray(scene.world_vertices)
         self._check(self.lib.fyprt_update_vertices(self.h, v.ctypes.data, len(v)))
+
+    def set_object_vertices(self, scene):
+        """Object-space vertices + per-mesh vertex ranges (scene.mesh_transforms), for update_transforms."""
+        v = np.ascontiguousarray(scene.vertices)
+        first = [tr["vertex_start"] for tr in scene.mesh_transforms] + [len(v)]
+        self._check(self.lib.fyprt_set_object_vertices(self.h, v.ctypes.data, len(v), (C.c_uint32 * len(first))(*first)))
+
+    def update_transforms(self, scene, mesh_indices):
+        """A transform edit applied on the device: 64 bytes per mesh (Scene.mesh_matrix) instead of its vertices."""
+        mats = np.ascontiguousarray(np.stack([scene.mesh_matrix(m) for m in mesh_indices]).astype(np.float32).reshape(-1))
+        idx = (C.c_uint32 * len(mesh_indices))(*[int(m) for m in mesh_indices])
+        self._check(self.lib.fyprt_update_transforms(self.h, idx, mats.ctypes.data_as(C.POINTER(C.c_float)), len(mesh_indices)))
+
+    def compare_image(self, reference, flip_reference_rows=False):
+        """(MSE, PSNR) of the current frame against `reference` (uint32 ABGR8, H x W), reduced on the device (MisUtils::ComputeMSE)."""
+        ref = np.ascontiguousarray(reference, dtype=np.uint32)
+        mse, psnr = C.c_double(), C.c_double()
+        self._check(self.lib.fyprt_compare_image(self.h, ref.ctypes.data, 1 if flip_reference_rows else 0, C.byref(mse), C.byref(psnr)))
+        return mse.value, psnr.value
 
     def get_tuning(self, key: int) -> int:
         v = C.c_int()

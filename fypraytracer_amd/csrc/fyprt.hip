@@ -3,6 +3,7 @@
 // frames (the reference re-allocates and round-trips ~100 MB over PCIe per 1080p frame,
 // Renderer.cu:37-53, :70, :244-283 — SURVEY.md §8 a14).
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -69,8 +70,12 @@ struct fyprt_context {
     // what a device refit needs beyond the tree itself (fyprt_update_vertices): vertices, per-triangle vertex indices, the nodes of
     // every level (bottom level first), a box per node; and the topology the host light-tree builder is fed again
     DevBuf<DevVertex> dverts; DevBuf<uint4> triIdx; DevBuf<uint32_t> levelNodes; DevBuf<float4> nodeBox; std::vector<uint32_t> levelOffset;
+    // fyprt_update_transforms: object-space vertices on the device, the meshes' vertex ranges, a host copy of the world vertices (the host
+    // light-tree builder reads the emissive meshes' vertices from it)
+    DevBuf<DevVertex> objVerts; std::vector<uint32_t> meshFirstVertex; std::vector<fyprt_vertex> hostVerts;
     std::vector<uint32_t> topoTris; std::vector<fyprt_mesh> topoMeshes; std::vector<fyprt_material> topoMats; uint32_t vertexCount = 0; bool prebuiltLightTrees = false;
     bool hostBvhStale = false;                      // the device tree was refitted: fyprt_export_bvh reads it back first
+    bool hostVertsStale = false;                    // world vertices were recomputed on the device: the host copy only follows for emissive meshes
     DevBuf<float4> nodes, leafTris, triPos, triShade, mats; DevBuf<DevTexture> texTable; std::vector<DevBuf<uint32_t>> texPixels;
     DevBuf<uint32_t> emissive; DevBuf<float4> lightRecs; DevBuf<DevLTNode> ltTlas, ltBlas; DevBuf<uint32_t> ltFirst, ltCount, ltRoot, ltLeafOfTri;
     DevBuf<unsigned long long> rayCounter;
@@ -85,6 +90,7 @@ struct fyprt_context {
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
     int pathOcc = 0; size_t pathOccLds = 0;     // cached residency of k_trace_rays
+    DevBuf<uint32_t> refImage;                 // fyprt_compare_image's reference
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -169,7 +175,7 @@ void fyprt_destroy(fyprt_context* c) {
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release(); c->ltLeafOfTri.release();
-    c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release();
+    c->rayCounter.release(); c->shadowTasks.release(); c->queueCounters.release(); c->refImage.release(); c->objVerts.release();
     for (int k = 0; k < 2; ++k) { c->wfRays[k].release(); c->wfHits[k].release(); }
     c->wfState.release(); c->wfPixels.release(); c->wfPixels2.release(); c->wfCounters.release();
     c->sortCounts.release(); c->sortOffset.release(); c->sortTotal.release(); c->sortIndex.release(); c->sortKeys.release(); c->sortHist.release();
@@ -362,6 +368,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     if (upload(c, c->triPos.p, pos.data(), c->triPos.bytes()) || upload(c, c->triShade.p, shade.data(), c->triShade.bytes())) return FYPRT_EHIP;
     // refit support: vertices + per-triangle indices on the device, nodes grouped by level (levels = 1 first)
     c->vertexCount = s->vertex_count; c->hostBvhStale = false;
+    c->hostVerts.assign(s->vertices, s->vertices + s->vertex_count); c->objVerts.release(); c->meshFirstVertex.clear();
     c->topoTris.resize((size_t)nT * 4);
     for (uint32_t i = 0; i < nT; ++i) std::memcpy(&c->topoTris[(size_t)i * 4], tri(i), 16);
     if (deviceBuild) {
@@ -481,10 +488,11 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
 
 
 // (Re)build the light trees from the given vertices with the stored topology and upload them (+ the emitter -> TLAS-leaf table).
-static int rebuild_light_trees(fyprt_context* c, const fyprt_vertex* verts) {
-    rth::LightTrees& lt = c->hostLt; lt = rth::LightTrees();
+static int rebuild_light_trees(fyprt_context* c, const fyprt_vertex* verts, const uint8_t* touched = nullptr) {
+    rth::LightTrees& lt = c->hostLt;
+    if (!touched) lt = rth::LightTrees();
     const uint32_t nT = (uint32_t)(c->topoTris.size() / 4), nM = (uint32_t)c->topoMeshes.size();
-    rth::BuildLightTrees(verts, (const uint8_t*)c->topoTris.data(), 16, c->topoMeshes.data(), nM, c->topoMats.data(), lt);
+    rth::BuildLightTrees(verts, (const uint8_t*)c->topoTris.data(), 16, c->topoMeshes.data(), nM, c->topoMats.data(), lt, touched);
     HIPCHK(c, c->ltTlas.alloc(lt.tlas.size())); HIPCHK(c, c->ltBlas.alloc(lt.blas.size()));
     HIPCHK(c, c->ltFirst.alloc(nM)); HIPCHK(c, c->ltCount.alloc(nM)); HIPCHK(c, c->ltRoot.alloc(nM));
     if (upload(c, c->ltTlas.p, lt.tlas.data(), c->ltTlas.bytes()) || upload(c, c->ltBlas.p, lt.blas.data(), c->ltBlas.bytes()) ||
@@ -520,11 +528,70 @@ int fyprt_update_vertices(fyprt_context* c, const fyprt_vertex* vertices, uint32
     HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
     const uint32_t nT = (uint32_t)(c->topoTris.size() / 4);
     if (upload(c, c->dverts.p, vertices, c->dverts.bytes())) return FYPRT_EHIP;
+    c->hostVerts.assign(vertices, vertices + vertex_count);
     if (nT) hipLaunchKernelGGL(k_refresh_triangles, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->dverts.p, c->triIdx.p, c->triPos.p, c->triShade.p, nT);
     { const int rr = run_refit(c); if (rr != FYPRT_OK) return rr; }
     c->hostBvhStale = true;
     int rc = rebuild_light_trees(c, vertices);
     if (rc != FYPRT_OK) return rc;
+    if (c->dsc.emissiveCount) hipLaunchKernelGGL(k_build_light_records, dim3((c->dsc.emissiveCount + 255u) / 256u), dim3(256), 0, c->stream, c->dsc, c->lightRecs.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, sync_all(c));
+    return FYPRT_OK;
+}
+
+// Object-space vertices (Scene::vertices) and the meshes' vertex ranges, kept on the device so that a transform edit can be applied there.
+int fyprt_set_object_vertices(fyprt_context* c, const fyprt_vertex* object_vertices, uint32_t vertex_count, const uint32_t* mesh_first_vertex) {
+    if (!c || !object_vertices || !mesh_first_vertex) return FYPRT_EINVAL;
+    if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_set_object_vertices before fyprt_upload_scene");
+    if (c->hostOnly) return c->fail(FYPRT_ESTATE, "fyprt_set_object_vertices needs a device (host-only context)");
+    if (vertex_count != c->vertexCount) return c->fail(FYPRT_EINVAL, "fyprt_set_object_vertices: vertex count differs from the uploaded scene");
+    const uint32_t nM = (uint32_t)c->topoMeshes.size();
+    for (uint32_t m = 0; m < nM; ++m) if (mesh_first_vertex[m] > mesh_first_vertex[m + 1] || mesh_first_vertex[m + 1] > vertex_count) return c->fail(FYPRT_EINVAL, "fyprt_set_object_vertices: mesh vertex ranges out of order / out of range");
+    // every triangle of a mesh must index into that mesh's vertex range (the transform of one mesh must not move another mesh's triangles)
+    for (uint32_t m = 0; m < nM; ++m)
+        for (uint32_t t = c->topoMeshes[m].first_triangle; t < c->topoMeshes[m].first_triangle + c->topoMeshes[m].triangle_count; ++t)
+            for (int k = 0; k < 3; ++k) { const uint32_t v = c->topoTris[(size_t)t * 4 + k]; if (v < mesh_first_vertex[m] || v >= mesh_first_vertex[m + 1]) return c->fail(FYPRT_EINVAL, "fyprt_set_object_vertices: triangle " + std::to_string(t) + " uses a vertex outside its mesh's range"); }
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
+    HIPCHK(c, c->objVerts.alloc(vertex_count));
+    if (upload(c, c->objVerts.p, object_vertices, c->objVerts.bytes())) return FYPRT_EHIP;
+    c->meshFirstVertex.assign(mesh_first_vertex, mesh_first_vertex + nM + 1);
+    return FYPRT_OK;
+}
+
+// A transform edit of `count` meshes (SceneManager::PerformAllSceneUpdates with meshTransformToBeUpdated, SceneManager.cpp:24-66): 64
+// bytes per mesh cross the bus; the world vertices are recomputed on the device (k_transform_vertices), per-triangle records, leaf
+// triangles, tree boxes and light records refreshed there, and only the moved EMISSIVE meshes' light trees are rebuilt on the host
+// (their vertices read back) + the small TLAS.  Same result as fyprt_update_vertices with host-computed world vertices.
+int fyprt_update_transforms(fyprt_context* c, const uint32_t* mesh_indices, const float* matrices16, uint32_t count) {
+    if (!c || (count && (!mesh_indices || !matrices16))) return FYPRT_EINVAL;
+    if (!c->haveScene || c->meshFirstVertex.empty()) return c->fail(FYPRT_ESTATE, "fyprt_update_transforms before fyprt_upload_scene + fyprt_set_object_vertices");
+    if (c->prebuiltLightTrees) return c->fail(FYPRT_ESTATE, "fyprt_update_transforms: the scene was uploaded with prebuilt light trees; upload it again instead");
+    const uint32_t nM = (uint32_t)c->topoMeshes.size(), nT = (uint32_t)(c->topoTris.size() / 4);
+    for (uint32_t k = 0; k < count; ++k) if (mesh_indices[k] >= nM) return c->fail(FYPRT_EINVAL, "fyprt_update_transforms: mesh index out of range");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
+    std::vector<uint8_t> touched(nM, 0);
+    bool lightsMoved = false;
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t m = mesh_indices[k], first = c->meshFirstVertex[m], n = c->meshFirstVertex[m + 1] - first;
+        Mat4 M; std::memcpy(M.m, matrices16 + (size_t)k * 16, 64);
+        if (n) hipLaunchKernelGGL(k_transform_vertices, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, c->objVerts.p, c->dverts.p, first, n, M);
+        const fyprt_material& mat = c->topoMats[c->topoMeshes[m].material_index];
+        const float ex = mat.emission_color[0] * mat.emission_power, ey = mat.emission_color[1] * mat.emission_power, ez = mat.emission_color[2] * mat.emission_power;
+        if (((ex * ex + ey * ey) + ez * ez) > 0.0f && n) {            // an emissive mesh moved: its light tree is rebuilt from its new vertices
+            HIPCHK(c, hipMemcpyAsync(c->hostVerts.data() + first, c->dverts.p + first, (size_t)n * sizeof(fyprt_vertex), hipMemcpyDeviceToHost, c->stream));
+            touched[m] = 1; lightsMoved = true;
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    if (nT) hipLaunchKernelGGL(k_refresh_triangles, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->dverts.p, c->triIdx.p, c->triPos.p, c->triShade.p, nT);
+    { const int rr = run_refit(c); if (rr != FYPRT_OK) return rr; }
+    c->hostBvhStale = true; c->hostVertsStale = true;
+    if (lightsMoved) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int rc = rebuild_light_trees(c, c->hostVerts.data(), touched.data());
+        if (rc != FYPRT_OK) return rc;
+    }
     if (c->dsc.emissiveCount) hipLaunchKernelGGL(k_build_light_records, dim3((c->dsc.emissiveCount + 255u) / 256u), dim3(256), 0, c->stream, c->dsc, c->lightRecs.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, sync_all(c));
@@ -853,6 +920,27 @@ int fyprt_readback(fyprt_context* c, uint32_t* rgba8, float* accum4) {
     const uint32_t* img = c->externalImage ? c->externalImage : c->image.p;
     if (rgba8) HIPCHK(c, hipMemcpy(rgba8 + off, img + off, cnt * 4, hipMemcpyDeviceToHost));
     if (accum4) HIPCHK(c, hipMemcpy(accum4 + off * 4, c->accum.p + off, cnt * 16, hipMemcpyDeviceToHost));
+    return FYPRT_OK;
+}
+
+// MisUtils::ComputeMSE / ComputePSNR (MisUtils.cpp:118-157) of the frame on the device against a host reference image (the benchmark
+// workflow of WalnutApp.cpp:826-876 without reading the frame back): RGB channels of the 8-bit images, this context's rows.
+int fyprt_compare_image(fyprt_context* c, const uint32_t* reference_rgba8, int flip_reference_rows, double* mse, double* psnr) {
+    if (!c || !reference_rgba8 || !mse) return FYPRT_EINVAL;
+    if (c->hostOnly || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_compare_image before fyprt_resize");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
+    const size_t n = (size_t)c->W * c->H;
+    if (c->refImage.n != n) HIPCHK(c, c->refImage.alloc(n));
+    if (upload(c, c->refImage.p, reference_rgba8, n * 4)) return FYPRT_EHIP;
+    HIPCHK(c, hipMemsetAsync(c->rayCounter.p + 31, 0, 8, c->stream));            // (the last, unused counter word serves as the accumulator)
+    const uint32_t* img = c->externalImage ? c->externalImage : c->image.p;
+    hipLaunchKernelGGL(k_image_sqdiff, dim3((uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, img, c->refImage.p, c->W, c->H, c->rowBegin, c->rowEnd, flip_reference_rows ? 1 : 0, c->rayCounter.p + 31);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long tot = 0;
+    HIPCHK(c, hipMemcpyAsync(&tot, c->rayCounter.p + 31, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mse = (double)tot / ((double)((size_t)(c->rowEnd - c->rowBegin) * c->W) * 3.0);
+    if (psnr) *psnr = (*mse == 0.0) ? (double)INFINITY : 10.0 * std::log10(255.0 * 255.0 / *mse);
     return FYPRT_OK;
 }
 

@@ -172,46 +172,64 @@ uint32_t buildSaoh(TreeOut& o, Item* w, uint32_t first, uint32_t last) {
 
 }  // namespace
 
+// BLAS of one emissive mesh (Mesh.cpp:176-207 leaf producers + ConstructLightTree): nodes appended to `nodes`, returns the root index
+// within them; `rootItem` = the TLAS leaf the mesh contributes (Scene.cpp:160-186)
+static uint32_t buildMeshBlas(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh& me, uint32_t meshIndex, float radiance,
+                              std::vector<fyprt_lighttree_node>& nodes, Item& rootItem) {
+    std::vector<Item> items(me.triangle_count);
+    for (uint32_t i = 0; i < me.triangle_count; ++i) {
+        const uint32_t t = me.first_triangle + i; const uint32_t* v = reinterpret_cast<const uint32_t*>(tris + (size_t)t * triStride);
+        const fyprt_vertex &a = verts[v[0]], &b = verts[v[1]], &c = verts[v[2]];
+        const V3 p0{a.position[0], a.position[1], a.position[2]}, p1{b.position[0], b.position[1], b.position[2]}, p2{c.position[0], c.position[1], c.position[2]};
+        const V3 n0{a.normal[0], a.normal[1], a.normal[2]}, n1{b.normal[0], b.normal[1], b.normal[2]}, n2{c.normal[0], c.normal[1], c.normal[2]};
+        Item& it = items[i];
+        it.payload = t; it.num = 1; it.pos = ((p0 + p1) + p2) / 3.0f;
+        auto mn = [](float x, float y) { return (y < x) ? y : x; }; auto mx = [](float x, float y) { return (x < y) ? y : x; };
+        it.box.lo = {mn(mn(p0.x, p1.x), p2.x), mn(mn(p0.y, p1.y), p2.y), mn(mn(p0.z, p1.z), p2.z)};
+        it.box.hi = {mx(mx(p0.x, p1.x), p2.x), mx(mx(p0.y, p1.y), p2.y), mx(mx(p0.z, p1.z), p2.z)};
+        it.box.c = (it.box.lo + it.box.hi) * 0.5f;
+        it.cone.te = kPi / 2.0f; it.cone.to = 0.0f; it.cone.axis = norm3(((n0 + n1) + n2) / 3.0f);
+        const V3 cr = cross3(p1 - p0, p2 - p0);
+        it.energy = ((0.5f * std::sqrt(dot3(cr, cr))) * radiance) * kPi;
+    }
+    TreeOut to;
+    const uint32_t root = buildSaoh(to, items.data(), 0, (uint32_t)items.size());
+    const NodeTmp rn = fromFlat(to.nodes[root]);
+    rootItem.energy = rn.energy; rootItem.num = rn.num; rootItem.cone = rn.cone; rootItem.box = rn.box; rootItem.pos = rn.box.c; rootItem.payload = meshIndex;
+    nodes.swap(to.nodes);
+    return root;
+}
+
+// `touched` == nullptr: build everything.  Otherwise `out` holds the trees of the same topology and only the meshes with
+// touched[m] != 0 get a new BLAS (a mesh's tree has 2n - 1 nodes whatever its geometry: replaced in place); the TLAS over the mesh
+// trees' roots is always rebuilt (it is small).  The result equals a full build bit for bit: a mesh's BLAS depends on that mesh alone.
 void BuildLightTrees(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
-                     uint32_t meshCount, const fyprt_material* mats, LightTrees& out) {
-    out = LightTrees();
-    out.first.assign(meshCount, 0); out.count.assign(meshCount, 0); out.root.assign(meshCount, ~0u);
+                     uint32_t meshCount, const fyprt_material* mats, LightTrees& out, const uint8_t* touched) {
+    const bool partial = touched != nullptr && out.first.size() == meshCount;
+    if (!partial) { out = LightTrees(); out.first.assign(meshCount, 0); out.count.assign(meshCount, 0); out.root.assign(meshCount, ~0u); }
     std::vector<Item> tlasItems;
     for (uint32_t m = 0; m < meshCount; ++m) {
         const fyprt_mesh& me = meshes[m]; const fyprt_material& mat = mats[me.material_index];
         const V3 em{mat.emission_color[0] * mat.emission_power, mat.emission_color[1] * mat.emission_power, mat.emission_color[2] * mat.emission_power};
-        out.first[m] = (uint32_t)out.blas.size();
+        if (!partial) out.first[m] = (uint32_t)out.blas.size();
         if (!(dot3(em, em) > 0.0f) || me.triangle_count == 0) continue;
-        const float radiance = std::sqrt(dot3(em, em));
-        std::vector<Item> items(me.triangle_count);
-        for (uint32_t i = 0; i < me.triangle_count; ++i) {
-            const uint32_t t = me.first_triangle + i; const uint32_t* v = reinterpret_cast<const uint32_t*>(tris + (size_t)t * triStride);
-            const fyprt_vertex &a = verts[v[0]], &b = verts[v[1]], &c = verts[v[2]];
-            const V3 p0{a.position[0], a.position[1], a.position[2]}, p1{b.position[0], b.position[1], b.position[2]}, p2{c.position[0], c.position[1], c.position[2]};
-            const V3 n0{a.normal[0], a.normal[1], a.normal[2]}, n1{b.normal[0], b.normal[1], b.normal[2]}, n2{c.normal[0], c.normal[1], c.normal[2]};
-            Item& it = items[i];
-            it.payload = t; it.num = 1; it.pos = ((p0 + p1) + p2) / 3.0f;
-            auto mn = [](float x, float y) { return (y < x) ? y : x; }; auto mx = [](float x, float y) { return (x < y) ? y : x; };
-            it.box.lo = {mn(mn(p0.x, p1.x), p2.x), mn(mn(p0.y, p1.y), p2.y), mn(mn(p0.z, p1.z), p2.z)};
-            it.box.hi = {mx(mx(p0.x, p1.x), p2.x), mx(mx(p0.y, p1.y), p2.y), mx(mx(p0.z, p1.z), p2.z)};
-            it.box.c = (it.box.lo + it.box.hi) * 0.5f;
-            it.cone.te = kPi / 2.0f; it.cone.to = 0.0f; it.cone.axis = norm3(((n0 + n1) + n2) / 3.0f);
-            const V3 cr = cross3(p1 - p0, p2 - p0);
-            it.energy = ((0.5f * std::sqrt(dot3(cr, cr))) * radiance) * kPi;
+        Item ti;
+        if (partial && !touched[m]) {                              // untouched: the TLAS leaf comes from the BLAS root that is already there
+            const NodeTmp rn = fromFlat(out.blas[out.first[m] + out.root[m]]);
+            ti.energy = rn.energy; ti.num = rn.num; ti.cone = rn.cone; ti.box = rn.box; ti.pos = rn.box.c; ti.payload = m;
+        } else {
+            std::vector<fyprt_lighttree_node> nodes;
+            const uint32_t root = buildMeshBlas(verts, tris, triStride, me, m, std::sqrt(dot3(em, em)), nodes, ti);
+            if (partial) std::copy(nodes.begin(), nodes.end(), out.blas.begin() + out.first[m]);
+            else out.blas.insert(out.blas.end(), nodes.begin(), nodes.end());
+            out.count[m] = (uint32_t)nodes.size(); out.root[m] = root;
         }
-        TreeOut to;
-        const uint32_t root = buildSaoh(to, items.data(), 0, (uint32_t)items.size());
-        out.count[m] = (uint32_t)to.nodes.size(); out.root[m] = root;
-        out.blas.insert(out.blas.end(), to.nodes.begin(), to.nodes.end());
-        const NodeTmp rn = fromFlat(to.nodes[root]);
-        Item ti; ti.energy = rn.energy; ti.num = rn.num; ti.cone = rn.cone; ti.box = rn.box; ti.pos = rn.box.c; ti.payload = m;
         tlasItems.push_back(ti);
     }
+    out.tlas.clear(); out.tlasRoot = ~0u;
     if (!tlasItems.empty()) {
         TreeOut to;
         // TLAS leaves keep the BLAS root's numEmitters (Scene.cpp:171-181 copies the node)
-        struct Fix { uint32_t num; };
-        std::vector<uint32_t> nums; for (auto& t : tlasItems) nums.push_back(t.num);
         out.tlasRoot = buildSaoh(to, tlasItems.data(), 0, (uint32_t)tlasItems.size());
         out.tlas.swap(to.nodes);
     }

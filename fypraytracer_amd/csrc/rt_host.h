@@ -45,7 +45,9 @@ struct LightTrees {
 };
 // Restatement of LightTree::ConstructLightTree (LightTree.cpp:4-340) + the leaf producers
 // (Mesh.cpp:176-207, Scene.cpp:160-186), in the flat node format of fyprt.h.
+// `touched` (one byte per mesh) != nullptr: `out` already holds the trees of this topology and only the touched meshes' trees are
+// rebuilt (vertices of the other meshes are not read), then the TLAS; the result equals a full build.
 void BuildLightTrees(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,
-                     uint32_t meshCount, const fyprt_material* mats, LightTrees& out);
+                     uint32_t meshCount, const fyprt_material* mats, LightTrees& out, const uint8_t* touched = nullptr);
 
 }  // namespace rth

@@ -27,6 +27,28 @@ __global__ void k_refresh_triangles(const DevVertex* verts, const uint4* triIdx,
     q[3] = make_float4(b.v, c.u, c.v, mat);
 }
 
+// World vertices of one mesh from its object-space vertices and its model matrix — the vertex loop of Scene::AddNewMeshToScene /
+// SceneManager::PerformAllSceneUpdates (Scene.cpp:42-51, SceneManager.cpp:30-41): position = (M * (p, 1)).xyz / w, normal =
+// normalize((M * (n, 0)).xyz) (the model matrix, not its inverse transpose), texture coordinates unchanged.  Operation order as in
+// host/HostTypes.h Mesh::ToWorld and scene.py Scene._to_world, so a transform edit uploads 64 bytes instead of the mesh's vertices.
+struct Mat4 { float m[16]; };      // column-major
+__global__ void k_transform_vertices(const DevVertex* obj, DevVertex* world, uint32_t first, uint32_t count, Mat4 M) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const DevVertex v = obj[first + k];
+    const float* m = M.m;
+    const float px = (m[0] * v.px + m[4] * v.py) + (m[8] * v.pz + m[12]);
+    const float py = (m[1] * v.px + m[5] * v.py) + (m[9] * v.pz + m[13]);
+    const float pz = (m[2] * v.px + m[6] * v.py) + (m[10] * v.pz + m[14]);
+    const float pw = (m[3] * v.px + m[7] * v.py) + (m[11] * v.pz + m[15]);
+    const float nx = (m[0] * v.nx + m[4] * v.ny) + (m[8] * v.nz);
+    const float ny = (m[1] * v.nx + m[5] * v.ny) + (m[9] * v.nz);
+    const float nz = (m[2] * v.nx + m[6] * v.ny) + (m[10] * v.nz);
+    const float inv = 1.0f / __builtin_sqrtf((nx * nx + ny * ny) + nz * nz);
+    DevVertex o; o.px = px / pw; o.py = py / pw; o.pz = pz / pw; o.nx = nx * inv; o.ny = ny * inv; o.nz = nz * inv; o.u = v.u; o.v = v.v;
+    world[first + k] = o;
+}
+
 __global__ void k_refresh_leaf_tris(const float4* triPos, float4* leafTris, uint32_t nLeaf) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nLeaf) return;
@@ -38,6 +60,25 @@ __global__ void k_refresh_leaf_tris(const float4* triPos, float4* leafTris, uint
     r[0] = make_float4(a.x, a.y, a.z, b.x - a.x);
     r[1] = make_float4(b.y - a.y, b.z - a.z, d.x - a.x, d.y - a.y);
     r[2] = make_float4(d.z - a.z, c.y, c.z, c.w);
+}
+
+// Sum of squared RGB differences of two ABGR8 images over rows [rowBegin, rowEnd) — MisUtils::ComputeMSE (MisUtils.cpp:118-147) as a
+// device reduction: exact integer arithmetic (3 x 255^2 per pixel into a 64-bit sum), so the MSE equals the host routine's bit for bit.
+// `flipRef`: the reference is read vertically flipped, as ComputeMSE reads its BMP-loaded original.
+__global__ __launch_bounds__(256) void k_image_sqdiff(const uint32_t* image, const uint32_t* ref, uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd, int flipRef, unsigned long long* sum) {
+    __shared__ unsigned long long s_part[4];
+    unsigned long long acc = 0;
+    const size_t n = (size_t)(rowEnd - rowBegin) * W;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const uint32_t y = rowBegin + (uint32_t)(k / W), x = (uint32_t)(k % W);
+        const uint32_t a = image[(size_t)y * W + x], b = ref[(size_t)(flipRef ? H - 1u - y : y) * W + x];
+#pragma unroll
+        for (int sft = 0; sft < 24; sft += 8) { const int d = (int)((a >> sft) & 0xFFu) - (int)((b >> sft) & 0xFFu); acc += (unsigned long long)(d * d); }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0u) atomicAdd(sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
 struct RBox { float lo[3], hi[3]; };
@@ -57,9 +98,16 @@ __global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32
     const int32_t child[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
     RBox cb[4]; RBox nb;
     const float big = 3.402823466e+38f;
+#pragma unroll
     for (int a = 0; a < 3; ++a) { nb.lo[a] = big; nb.hi[a] = -big; }
-    for (uint32_t i = 0; i < cnt; ++i) {
-        RBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = big; b.hi[a] = -big; }
+    // (every loop over the four child slots and the three axes is fully unrolled and predicated on `i < cnt`: the per-child boxes are
+    // then indexed by constants and live in registers — indexed dynamically they were 112 bytes of scratch per lane)
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        RBox b;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { b.lo[a] = big; b.hi[a] = -big; }
+        if (i >= cnt) { cb[i] = b; continue; }
         if (child[i] >= 0) {
             const float4 l = nodeBox[(size_t)child[i] * 2], h = nodeBox[(size_t)child[i] * 2 + 1];
             b.lo[0] = l.x; b.lo[1] = l.y; b.lo[2] = l.z; b.hi[0] = h.x; b.hi[1] = h.y; b.hi[2] = h.z;
@@ -73,9 +121,11 @@ __global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32
             }
         }
         cb[i] = b;
+#pragma unroll
         for (int a = 0; a < 3; ++a) { nb.lo[a] = __builtin_fminf(nb.lo[a], b.lo[a]); nb.hi[a] = __builtin_fmaxf(nb.hi[a], b.hi[a]); }
     }
     uint32_t exps = ex & 0xFF000000u, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float lo = nb.lo[a];
         const double ext = (double)nb.hi[a] - (double)lo;
@@ -86,6 +136,7 @@ __global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32
             const double s = ldexp(1.0, e - 127); const float sf = (float)s;
             bool ok = ext <= 254.0 * s;
             wl = 0; wh = 0;
+#pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
                 int ql = 255, qh = 0;                                  // unused slots: the inverted box no ray can hit
                 if (i < cnt && ok) {

@@ -126,7 +126,7 @@ struct Scene {
 };
 
 template <class RendererT> void SceneManager::PerformAllSceneUpdates(Scene& scene, RendererT& renderer) {   // SceneManager.cpp:6-130
-    if (!materialsToUpdate.empty()) renderer.SetSceneToBeUpdatedFlag(true);
+    if (!materialsToUpdate.empty()) { renderer.SetSceneToBeUpdatedFlag(true); renderer.NoteOtherSceneEdit(); }
     for (const MeshUpdateParam& u : meshesToUpdate) {
         if (!(u.meshTransformToBeUpdated || u.meshMatToBeUpdated)) continue;
         Mesh& mesh = scene.meshes[u.meshIndex];
@@ -137,10 +137,11 @@ template <class RendererT> void SceneManager::PerformAllSceneUpdates(Scene& scen
                 scene.worldVertices[mesh.vertexStart + i].position = w.position; scene.worldVertices[mesh.vertexStart + i].normal = w.normal;
             }
             renderer.SetSceneToBeUpdatedFlag(true);
+            renderer.NoteMeshTransform(u.meshIndex, mesh.worldTransformMatrix.m);       // (the one line a maintainer adds to SceneManager.cpp:41)
         }
         if (u.meshMatToBeUpdated) {
             for (uint32_t t = mesh.indexStart / 3; t < mesh.indexStart / 3 + mesh.indexCount / 3; ++t) scene.triangles[t].materialIndex = mesh.materialIndex;
-            renderer.SetSceneToBeUpdatedFlag(true);
+            renderer.SetSceneToBeUpdatedFlag(true); renderer.NoteOtherSceneEdit();
         }
     }
     meshesToUpdate.clear(); materialsToUpdate.clear();

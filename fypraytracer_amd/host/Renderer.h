@@ -50,7 +50,12 @@ public:
         if (isSceneUpdated) {                                                                 // :61-69
             // only vertices moved since the last upload (a transform edit): refit on the device instead of a full rebuild
             const uint64_t sig = TopologySignature(scene);
-            if (m_HaveScene && sig == m_TopologySig &&
+            // (a) nothing but mesh transforms changed and the SceneManager told us which (NoteMeshTransform): 64 bytes per mesh go to the
+            //     device, which recomputes the world vertices itself;  (b) same topology: every world vertex is uploaded, refit on the device
+            if (m_HaveScene && sig == m_TopologySig && !m_PendingTransforms.empty() && !m_OtherEdits &&
+                fyprt_update_transforms(m_Ctx, m_PendingMeshes.data(), m_PendingTransforms.data(), (uint32_t)m_PendingMeshes.size()) == FYPRT_OK) {
+                ++m_Refits; ++m_TransformUpdates;
+            } else if (m_HaveScene && sig == m_TopologySig &&
                 fyprt_update_vertices(m_Ctx, reinterpret_cast<const fyprt_vertex*>(scene.worldVertices.data()), (uint32_t)scene.worldVertices.size()) == FYPRT_OK) {
                 ++m_Refits;
             } else if (UploadScene(scene)) {                 // remember the topology only of a scene the library really holds
@@ -58,7 +63,7 @@ public:
             } else {
                 m_HaveScene = false;
             }
-            isSceneUpdated = false;
+            isSceneUpdated = false; m_PendingMeshes.clear(); m_PendingTransforms.clear(); m_OtherEdits = false;
         }
         fyprt_camera_desc c{};                                                                // :70 CameraToGPU
         std::memcpy(c.projection, &camera.GetProjection(), 64); std::memcpy(c.view, &camera.GetView(), 64);
@@ -85,6 +90,12 @@ public:
     void ResizePrimaryHitPayloadBuffers(uint32_t w, uint32_t h) { Rezero(w, h); }
     void FreeDynamicallyAllocatedMemory() { if (m_Ctx) { fyprt_destroy(m_Ctx); m_Ctx = nullptr; } }
     void SetSceneToBeUpdatedFlag(bool flag) { isSceneUpdated = flag; }
+    // Called by SceneManager::PerformAllSceneUpdates next to SetSceneToBeUpdatedFlag for a mesh whose transform changed (its
+    // Mesh::worldTransformMatrix, column-major) — lets Render() send the matrix instead of the mesh's vertices.  Any other edit
+    // (material change, ...) is reported with NoteOtherSceneEdit() and takes the general path.
+    void NoteMeshTransform(uint32_t meshIndex, const float* matrix16) { m_PendingMeshes.push_back(meshIndex); m_PendingTransforms.insert(m_PendingTransforms.end(), matrix16, matrix16 + 16); }
+    void NoteOtherSceneEdit() { m_OtherEdits = true; }
+    uint32_t GetTransformUpdateCount() const { return m_TransformUpdates; }
     void SetPresenter(std::function<void(const uint32_t*, uint32_t, uint32_t)> p) { m_Present = std::move(p); }
     const fyprt_frame_stats& GetLastFrameStats() const { return m_LastStats; }
     fyprt_context* GetContext() const { return m_Ctx; }
@@ -122,7 +133,14 @@ private:
         d.emissive_triangles = scene.emissiveTriangles.empty() ? nullptr : scene.emissiveTriangles.data();
         d.emissive_count = (uint32_t)scene.emissiveTriangles.size();
         d.light_trees = nullptr;                      // the library builds them (LightTree.cpp restated)
-        return !report(fyprt_upload_scene(m_Ctx, &d), "fyprt_upload_scene");
+        if (report(fyprt_upload_scene(m_Ctx, &d), "fyprt_upload_scene")) return false;
+        // object-space vertices + mesh vertex ranges: what fyprt_update_transforms needs (Scene::vertices, Mesh::vertexStart / vertexCount)
+        if (scene.vertices.size() == scene.worldVertices.size()) {
+            std::vector<uint32_t> first(scene.meshes.size() + 1, (uint32_t)scene.vertices.size());
+            for (size_t i = 0; i < scene.meshes.size(); ++i) first[i] = scene.meshes[i].vertexStart;
+            fyprt_set_object_vertices(m_Ctx, reinterpret_cast<const fyprt_vertex*>(scene.vertices.data()), (uint32_t)scene.vertices.size(), first.data());
+        }
+        return true;
     }
     void Rezero(uint32_t w, uint32_t h) { m_Width = m_Height = 0; OnResize(w, h); }
     bool report(int rc, const char* what) {          // the reference prints and keeps going (Renderer.cu:29-47)
@@ -136,7 +154,8 @@ private:
     std::vector<uint32_t> m_RenderImageData;
     std::vector<float> m_AccumulationData;
     bool isSceneUpdated = true;
-    bool m_HaveScene = false; uint64_t m_TopologySig = 0; uint32_t m_Uploads = 0, m_Refits = 0;
+    bool m_HaveScene = false; uint64_t m_TopologySig = 0; uint32_t m_Uploads = 0, m_Refits = 0, m_TransformUpdates = 0;
+    std::vector<uint32_t> m_PendingMeshes; std::vector<float> m_PendingTransforms; bool m_OtherEdits = false;
     std::function<void(const uint32_t*, uint32_t, uint32_t)> m_Present;
     fyprt_frame_stats m_LastStats{};
 };

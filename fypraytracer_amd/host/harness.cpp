@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
     s.useTemporalReuse = s.useSpatialReuse = true;
     renderer.OnResize(W, H); camera.OnResize(W, H); camera.SetPosition({0, 0, 3.4f});
     double total = 0.0;
+    scene.sceneManager.PerformAllSceneUpdates(scene, renderer);   // MainLayer::OnUpdate calls it every frame (WalnutApp.cpp:776); the first call drains the 20 default queue entries
     for (int f = 0; f < frames; ++f) {
         s.randSeed++;                                                                       // WalnutApp.cpp:532
         const auto t0 = std::chrono::steady_clock::now();
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
         s.randSeed++;
         renderer.Render(scene, camera);
     }
-    std::printf("Scene uploads : %u, device refits : %u\n", renderer.GetSceneUploadCount(), renderer.GetSceneRefitCount());
+    std::printf("Scene uploads : %u, device refits : %u (of them by matrix alone : %u)\n", renderer.GetSceneUploadCount(), renderer.GetSceneRefitCount(), renderer.GetTransformUpdateCount());
     std::printf("Resolution : %ux%u\nTriangles : %zu\nAvg frame time : %.3fms (kernels %.3fms)\nAccumulated frames : %u\n",
                 W, H, scene.triangles.size(), total / frames, renderer.GetLastFrameStats().kernel_ms, renderer.GetCurrentFrameIndex() - 1);
     if (argc > 5 && !MisUtils::SaveABGRToBMP(argv[5], renderer.GetRenderImageDataPtr(), (int)W, (int)H)) { std::fprintf(stderr, "cannot write %s\n", argv[5]); return 1; }

@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include "HostTypes.h"
 using namespace fyprt_host;
-struct FlagOnly { bool dirty = false; void SetSceneToBeUpdatedFlag(bool f) { dirty = f; } };
+struct FlagOnly { bool dirty = false; void SetSceneToBeUpdatedFlag(bool f) { dirty = f; } void NoteMeshTransform(uint32_t, const float*) {} void NoteOtherSceneEdit() {} };
 int main(int argc, char** argv) {
     if (argc != 10 && argc != 16) return 2;
     float a[15] = {0}; for (int i = 1; i < argc; ++i) a[i - 1] = (float)std::atof(argv[i]);

@@ -249,6 +249,12 @@ class Scene:
         wn = (n4[:, :3] * (F(1) / nl)[:, None]).astype(F)
         return wp, wn
 
+    def mesh_matrix(self, mesh_index):
+        """Mesh::worldTransformMatrix of a mesh ([col][row] float32): T * yawPitchRoll(ry, rx, rz) * S (Mesh::UpdateWorldTransform)."""
+        tr = self.mesh_transforms[mesh_index]
+        rot = tr["rotation"]
+        return _matmul(_matmul(translate(tr["pos"]), yaw_pitch_roll(math.radians(rot[1]), math.radians(rot[0]), math.radians(rot[2]))), scale(tr["scale"]))
+
     def add_new_mesh_to_scene(self, positions, normals, uvs, indices, pos=(0, 0, 0), rotation=(0, 0, 0),
                               scale_=(1, 1, 1), material_index=0):
         """Scene::AddNewMeshToScene (Scene.cpp:9-92): transform = T * yawPitchRoll(ry, rx, rz) * S,

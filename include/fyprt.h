@@ -278,6 +278,21 @@ int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
  * traversal must use too). */
 int fyprt_get_tuning(fyprt_context* ctx, int key, int* value);
 
+/* Scene::vertices (object space) + every mesh's vertex range [mesh_first_vertex[m], mesh_first_vertex[m+1]) (Mesh::vertexStart /
+ * vertexCount), kept on the device so that fyprt_update_transforms can apply a transform edit there.  After fyprt_upload_scene. */
+int fyprt_set_object_vertices(fyprt_context* ctx, const fyprt_vertex* object_vertices, uint32_t vertex_count, const uint32_t* mesh_first_vertex);
+/* A transform edit of `count` meshes — SceneManager::PerformAllSceneUpdates with meshTransformToBeUpdated (SceneManager.cpp:24-66),
+ * i.e. Mesh::worldTransformMatrix (column-major glm::mat4, 16 floats per listed mesh) applied to the mesh's object-space vertices as
+ * Scene.cpp:42-51 does (position / w; normal by the model matrix with w = 0, normalised).  64 bytes per mesh cross the bus; world
+ * vertices, per-triangle records, tree boxes and light records are refreshed on the device, the light trees of the moved emissive
+ * meshes (+ the TLAS) on the host.  Same result as fyprt_update_vertices with the host-computed world vertices. */
+int fyprt_update_transforms(fyprt_context* ctx, const uint32_t* mesh_indices, const float* matrices16, uint32_t count);
+
+/* MisUtils::ComputeMSE / ComputePSNR (MisUtils.cpp:118-157) of the current frame against a host reference image, reduced on the
+ * device (exact integer sums: equals the host routine bit for bit); `flip_reference_rows` reads the reference vertically flipped as
+ * ComputeMSE reads its BMP original.  The benchmark workflow of WalnutApp.cpp:826-876 without a read-back.  `psnr` may be NULL. */
+int fyprt_compare_image(fyprt_context* ctx, const uint32_t* reference_rgba8, int flip_reference_rows, double* mse, double* psnr);
+
 /* ================================================================================================= multi-GPU
  * The reference renders on one GPU (Renderer.cu:13-284); there is no reference interface for this section.  It splits ONE
  * Renderer::Render call over several GPUs by image rows: every GPU holds the whole scene and renders a band;

@@ -77,7 +77,7 @@ def test_cpp_harness_runs(tmp_path):
     r = subprocess.run([str(exe), "7", "8", "128", "128", str(bmp)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "Accumulated frames : 9" in r.stdout          # 8 frames + the one after the SceneManager transform edit
-    assert "Scene uploads : 1, device refits : 1" in r.stdout   # the edit went through fyprt_update_vertices, not a rebuild
+    assert "Scene uploads : 1, device refits : 1 (of them by matrix alone : 1)" in r.stdout   # the edit went to the device as one 4x4 matrix, not as vertices, not as a rebuild
     data = bmp.read_bytes()
     assert data[:2] == b"BM" and len(data) == 54 + 128 * 128 * 3
     px = np.frombuffer(data[54:], dtype=np.uint8)
