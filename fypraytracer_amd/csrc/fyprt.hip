@@ -85,7 +85,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[14] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[15] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
@@ -818,7 +818,9 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
                 q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p + sg; q.keys = c->sortKeys.p + sg * 256u; q.hist = c->sortHist.p + sg * kSortBins;
                 q.binOffset = c->sortOffset.p + sg * kSortBins; q.binTotal = c->sortTotal.p + (size_t)par * kSortBins; q.sorted = c->sortIndex.p + sg * 256u;
                 HIPCHK(c, hipMemsetAsync(q.counters, 0, 16, fs));
-                hipLaunchKernelGGL(k_di_part2_setup, grid, block, 0, fs, c->dsc, c->dcam, fr, st, q);
+                if (c->tuning[14] == 1) hipLaunchKernelGGL(k_di_part2_setup<1>, grid, block, 0, fs, c->dsc, c->dcam, fr, st, q);
+                else if (c->tuning[14] == 2) hipLaunchKernelGGL(k_di_part2_setup<2>, grid, block, 0, fs, c->dsc, c->dcam, fr, st, q);
+                else hipLaunchKernelGGL(k_di_part2_setup<0>, grid, block, 0, fs, c->dsc, c->dcam, fr, st, q);
                 if (q.sortMode) {
                     hipLaunchKernelGGL(k_di_sort_scan, dim3(kSortBins), block, 0, fs, q);
                     hipLaunchKernelGGL(k_di_sort_scatter, grid, block, 0, fs, q);
@@ -1027,17 +1029,17 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 14) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 15) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 14) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 15) return FYPRT_EINVAL;
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
-    static const int lo[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[14] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1, 1};
+    static const int lo[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int hi[15] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1, 1, 2};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

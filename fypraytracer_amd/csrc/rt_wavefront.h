@@ -33,10 +33,109 @@ constexpr uint32_t kNoRayTask = 0xFFFFFFFFu;   // light-triangle field of a task
 constexpr uint32_t kSortBins = 64;   // counters[0] = tail (tasks appended), [1] = head (tasks taken)
 constexpr int kRefillLanes = 16;
 
+// ---- spatial reuse with SPECULATIVE neighbour gathers (R.cu:1913-1941).
+// The reference's loop is a chain of dependent gathers: neighbour k's pixel comes from the random stream, and the stream advances by
+// one more draw when neighbour k-1 was ACCEPTED (its reservoir update draws a number) — so the address of gather k is only known after
+// gather k-1 has returned and been tested.  But acceptance depends on geometry alone (depth, normal), and the stream position before
+// neighbour k only on HOW MANY of the k earlier neighbours were accepted: 2k + a draws, a = 0..k.  So every address the loop can
+// possibly visit is known up front — 1 + 2 + ... + N candidates (15 for N = 5) — and all of them are fetched at once (16-byte hot
+// half of the record: depth, normal, light index); the accept / reject walk then runs on registers, and the second halves (W, pdf, M)
+// of the <= N accepted records are fetched in one more round.  Two memory round trips instead of N dependent ones; every number
+// (addresses, random draws, update order) is the serial loop's.  N > kSpecNeighbors falls back to the serial loop.
+// MEASURED SLOWER (tuning key 14, default off): 0.259 vs 0.225 ms on the bench frame — 15 hot quads in flight cost 152 VGPRs (3 waves per
+// SIMD instead of 7) and three times the gather requests, while at 7 waves the dependent round trips were already hidden; the kernel
+// moves 0.85 GB of HBM in 0.225 ms and is bound by that and by the gather request rate, not by latency (profiles/README.md r02).
+constexpr int kSpecNeighbors = 5;
+RT_DEV uint32_t neighbor_from_states(const DevCamera& cam, uint32_t W, uint32_t x, uint32_t y, uint32_t radius, uint32_t s1, uint32_t s2) {   // == neighbor_index with explicit draws
+    float ox = 2.0f * ((float)s1 * 0x1p-32f) - 1.0f, oy = 2.0f * ((float)s2 * 0x1p-32f) - 1.0f;
+    ox = (float)(uint32_t)(x + (uint32_t)(int)(ox * (float)radius));
+    oy = (float)(uint32_t)(y + (uint32_t)(int)(oy * (float)radius));
+    ox = __builtin_fmaxf(0.0f, __builtin_fminf((float)cam.W - 1.0f, ox));
+    oy = __builtin_fmaxf(0.0f, __builtin_fminf((float)cam.H - 1.0f, oy));
+    return (uint32_t)ox + (uint32_t)oy * W;
+}
+// S: the reservoir being built (already holding the pixel's own sample), Z its normalisation count; returns the stream state after the loop
+RT_DEV uint32_t spatial_reuse_speculative(const DevCamera& cam, const DevFrame& fr, const DevSettings& st, uint32_t x, uint32_t y, const Payload& pp, uint32_t seed, DIRes& S, uint32_t& Z) {
+    const uint32_t N = st.numNeighbors;
+    uint32_t xs[3 * kSpecNeighbors + 1];                               // xs[j] = the stream state after j draws
+    xs[0] = seed;
+#pragma unroll
+    for (int j = 1; j <= 3 * kSpecNeighbors; ++j) xs[j] = pcg_hash(xs[j - 1]);
+    float4 hot[kSpecNeighbors * (kSpecNeighbors + 1) / 2]; uint32_t nis[kSpecNeighbors * (kSpecNeighbors + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < kSpecNeighbors; ++k)
+#pragma unroll
+        for (int a = 0; a <= k; ++a) {
+            const int c = k * (k + 1) / 2 + a;
+            nis[c] = neighbor_from_states(cam, fr.W, x, y, st.radius, xs[2 * k + a + 1], xs[2 * k + a + 2]);
+            hot[c] = ((uint32_t)k < N) ? reinterpret_cast<const float4*>(fr.drec + nis[c])[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    // the walk: which candidate each neighbour really is, and whether it passes the geometry test
+    uint32_t acc = 0;                                                  // neighbours accepted so far
+    uint32_t useNi[kSpecNeighbors]; bool use[kSpecNeighbors]; uint32_t draw[kSpecNeighbors], lightIdx[kSpecNeighbors];
+#pragma unroll
+    for (int k = 0; k < kSpecNeighbors; ++k) {
+        float4 h = hot[k * (k + 1) / 2]; uint32_t ni = nis[k * (k + 1) / 2]; uint32_t d = xs[2 * k + 3];
+#pragma unroll
+        for (int a = 1; a <= k; ++a) if (acc == (uint32_t)a) { h = hot[k * (k + 1) / 2 + a]; ni = nis[k * (k + 1) / 2 + a]; d = xs[2 * k + a + 3]; }
+        const float nd = h.x, pdp = pp.hitDistance;
+        f2 nn; nn.x = h.y; nn.y = h.z;
+        const bool ok = (uint32_t)k < N && !((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nn)) < 0.906);
+        use[k] = ok; useNi[k] = ni; draw[k] = d; lightIdx[k] = (uint32_t)__float_as_int(h.w);
+        acc += ok ? 1u : 0u;
+    }
+    // second halves of the accepted records, all in flight together
+    float4 cold[kSpecNeighbors];
+#pragma unroll
+    for (int k = 0; k < kSpecNeighbors; ++k) cold[k] = use[k] ? reinterpret_cast<const float4*>(fr.drec + useNi[k])[1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < kSpecNeighbors; ++k) {
+        if (!use[k]) continue;
+        const float Wn = cold[k].x, pdf = cold[k].y; const uint32_t M = (uint32_t)__float_as_int(cold[k].w);
+        // di_update(S, index, (pdf * W) * M, M, pdf, seed) with the draw the serial loop makes at this point
+        const float w = (pdf * Wn) * (float)M;
+        S.wSum += w; S.M += M;
+        if ((float)draw[k] * 0x1p-32f < w / S.wSum) { S.index = lightIdx[k]; S.pdf = pdf; }
+        Z += pdf > 0.0f ? M : 0u;
+    }
+    uint32_t out = xs[2 * kSpecNeighbors];                             // state after N neighbours with `acc` accepted: xs[2N + acc]
+#pragma unroll
+    for (int j = 0; j <= 3 * kSpecNeighbors; ++j) if ((uint32_t)j == 2u * N + acc) out = xs[j];
+    return out;
+}
+
+// MODE 0: one dependent 32-byte gather per neighbour (default).  1: speculative gathers (above).  2: the north-star's "reservoir
+// neighbourhood in LDS" — the workgroup's 16x16 tile + `radius` pixels all round (76 x 76 for radius 30) of the 12-byte hot fields
+// (depth, octahedral normal) staged in LDS (69 KB), the geometry test served from there, the rest of an ACCEPTED neighbour's record
+// fetched from memory.  Measured (tuning key 14 = 2) and NOT the default: see the numbers in profiles/README.md r02 — the tile samples
+// 5 x 256 of its 5776 window entries, so staging moves 4.5x the bytes the gathers touch, and 69 KB of LDS leave two workgroups per CU.
+constexpr int kWinMax = 16 + 2 * 30;
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
+    constexpr bool SPECULATIVE = MODE == 1;
     uint32_t x, y;
     const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
     const uint32_t i = x + y * fr.W;
+    __shared__ float s_win[MODE == 2 ? 3 * kWinMax * kWinMax : 1];
+    __shared__ uint32_t s_org[4];
+    uint32_t wx0 = 0, wy0 = 0, ww = 0, wh = 0;
+    if (MODE == 2) {
+        if (threadIdx.x == 0u) { s_org[0] = inside ? x : 0xFFFFFFFFu; s_org[1] = y; }
+        __syncthreads();
+        const bool tileOk = s_org[0] != 0xFFFFFFFFu && st.radius <= 30u;      // (thread 0 owns the tile's first pixel: outside => the whole tile is)
+        if (tileOk) {
+            const uint32_t tx0 = s_org[0], ty0 = s_org[1], R = st.radius;
+            wx0 = tx0 > R ? tx0 - R : 0u; wy0 = ty0 > R ? ty0 - R : 0u;
+            const uint32_t wx1 = (tx0 + 16u + R < fr.W) ? tx0 + 16u + R : fr.W, wy1 = (ty0 + 16u + R < fr.H) ? ty0 + 16u + R : fr.H;
+            ww = wx1 - wx0; wh = wy1 - wy0;
+            for (uint32_t k = threadIdx.x; k < ww * wh; k += (uint32_t)kBlock) {
+                const uint32_t px = wx0 + k % ww, py = wy0 + k / ww;
+                const float4 h = reinterpret_cast<const float4*>(fr.drec + ((size_t)py * fr.W + px))[0];
+                s_win[k] = h.x; s_win[kWinMax * kWinMax + k] = h.y; s_win[2 * kWinMax * kWinMax + k] = h.z;
+            }
+        }
+        __syncthreads();
+    }
     // Which pixels continue into Part 2 is the reference's sentinel test (Renderer.cu:2787) — here derived from the payload
     // with Part 1's own expressions instead of read back from the image: a pixel that saw the sky or an emitter is finished
     // (R.cu:1650-1668) and becomes a task WITHOUT a ray that only carries its colour to the epilogue, so that Part 1 writes
@@ -60,7 +159,21 @@ __global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamer
         if (st.useSpatial) {
             uint32_t Z = 0; DIRes S = di_empty();
             { const float pdf = R.pdf; di_update(S, R.index, (pdf * R.W) * (float)R.M, R.M, pdf, seed); Z += pdf > 0.0f ? R.M : 0u; }
-            for (uint32_t n = 0; n < st.numNeighbors; ++n) {
+            if (SPECULATIVE && st.numNeighbors <= (uint32_t)kSpecNeighbors) seed = spatial_reuse_speculative(cam, fr, st, x, y, pp, seed, S, Z);
+            else if (MODE == 2 && ww != 0u) for (uint32_t n = 0; n < st.numNeighbors; ++n) {
+                const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+                const uint32_t nxp = ni % fr.W, nyp = ni / fr.W;
+                float nd; f2 nn;
+                if (nxp - wx0 < ww && nyp - wy0 < wh) { const uint32_t k = (nyp - wy0) * ww + (nxp - wx0); nd = s_win[k]; nn.x = s_win[kWinMax * kWinMax + k]; nn.y = s_win[2 * kWinMax * kWinMax + k]; }
+                else { const float4 h = reinterpret_cast<const float4*>(fr.drec + ni)[0]; nd = h.x; nn.x = h.y; nn.y = h.z; }     // the unsigned wrap lands outside the window
+                const float pdp = pp.hitDistance;
+                if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nn)) < 0.906) continue;
+                const DIRes N = rec_reservoir(load_rec(fr.drec + ni));          // accepted: the reservoir half comes from memory
+                const float pdf = N.pdf;
+                di_update(S, N.index, (pdf * N.W) * (float)N.M, N.M, pdf, seed);
+                Z += pdf > 0.0f ? N.M : 0u;
+            }
+            else for (uint32_t n = 0; n < st.numNeighbors; ++n) {
                 const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
                 const DIRec nb = load_rec(fr.drec + ni);                       // one 32-byte gather per neighbour
                 const float nd = nb.hitDistance, pdp = pp.hitDistance;

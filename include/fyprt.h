@@ -272,7 +272,12 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties).
  * key 13: MEASUREMENT ONLY (tools/band_rate.py): 1 = a lone context skips ReSTIR Part 1 on its halo rows as a band does in halo-exchange
  *        mode, without anybody filling them — the cost of one band of an exchange-mode split; the image near the band border is not valid.
- * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 12, 13: 0..1, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
+ * key 14: 1 = ReSTIR DI Part-2 setup fetches every neighbour record the spatial-reuse loop can possibly visit at once (the addresses
+ *        depend only on how many earlier neighbours were accepted) instead of one dependent gather per neighbour; same results.
+ *        Default 0: measured slower (0.259 vs 0.225 ms) — register pressure and request rate outweigh the saved round trips.
+ *        2 = the reservoir neighbourhood's hot fields (depth, normal; 12 B) of the workgroup's 76 x 76 pixel window staged in LDS (69 KB),
+ *        the geometry test served from there; same results; measured slower as well (profiles/README.md r02).
+ * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 12, 13: 0..1, key 14: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
  * traversal must use too). */
