@@ -63,7 +63,7 @@ struct fyprt_context {
     bool haveScene = false, haveCamera = false, countRays = false;
     // per-pixel buffers
     DevBuf<float4> accum; DevBuf<uint32_t> image; DevBuf<Payload> payload; DevBuf<float> depth; DevBuf<f2> normalA, normalB;
-    DevBuf<DIRes> di, diPrev; DevBuf<GIRes> gi, giPrev; bool normalFlip = false;
+    DevBuf<DIRes> di, diPrev; DevBuf<GIRes> gi, giPrev; DevBuf<float4> giHot; bool normalFlip = false;
     DevBuf<DIRec> drec, dprevA, dprevB; bool dprevFlip = false; int lastTech = -1;
     uint32_t* externalImage = nullptr;
     // scene
@@ -171,7 +171,7 @@ void fyprt_destroy(fyprt_context* c) {
     (void)sync_all(c);
     fyprt_comm_destroy(c);
     c->accum.release(); c->image.release(); c->payload.release(); c->depth.release(); c->normalA.release(); c->normalB.release();
-    c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release(); c->drec.release(); c->dprevA.release(); c->dprevB.release();
+    c->di.release(); c->diPrev.release(); c->gi.release(); c->giPrev.release(); c->giHot.release(); c->drec.release(); c->dprevA.release(); c->dprevB.release();
     c->nodes.release(); c->leafTris.release(); c->triPos.release(); c->triShade.release(); c->mats.release(); c->texTable.release();
     for (auto& t : c->texPixels) t.release();
     c->emissive.release(); c->lightRecs.release(); c->ltTlas.release(); c->ltBlas.release(); c->ltFirst.release(); c->ltCount.release(); c->ltRoot.release(); c->ltLeafOfTri.release();
@@ -197,7 +197,8 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     const size_t n = (size_t)w * h;
     HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
     HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
-    HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n));
+    HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n)); HIPCHK(c, c->giHot.alloc(n));
+    HIPCHK(c, hipMemsetAsync(c->giHot.p, 0, c->giHot.bytes(), c->stream));
     HIPCHK(c, c->drec.alloc(n)); HIPCHK(c, c->dprevA.alloc(n)); HIPCHK(c, c->dprevB.alloc(n));
     HIPCHK(c, hipMemsetAsync(c->drec.p, 0, c->drec.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->dprevA.p, 0, c->dprevA.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->dprevB.p, 0, c->dprevB.bytes(), c->stream));
@@ -659,7 +660,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
     DevFrame fr;
     fr.accum = c->accum.p; fr.image = c->externalImage ? c->externalImage : c->image.p; fr.payload = c->payload.p; fr.depth = c->depth.p;
     fr.normalPrev = c->normalFlip ? c->normalB.p : c->normalA.p; fr.normalCur = c->normalFlip ? c->normalA.p : c->normalB.p;
-    fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p;
+    fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p; fr.giHot = c->giHot.p;
     fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
     fr.histBegin = (tech == FYPRT_RESTIR_GI) ? c->histGI[0] : c->histDI[0]; fr.histEnd = (tech == FYPRT_RESTIR_GI) ? c->histGI[1] : c->histDI[1];

@@ -7,7 +7,7 @@
 //                            border differ (unbiased) from a single-GPU frame;
 //   exchange  (halo mode 1)  every band runs Part 1 on its own rows only; between Part 1 and Part 2 it receives the Part-1 records of
 //                            its halo rows from the bands that own them, and before Part 1 their temporal history — 32 B per pixel
-//                            and exchange for ReSTIR DI (1.8 MB per neighbour at 1080p), 120 B + 72 B for ReSTIR GI.  Every record is
+//                            and exchange for ReSTIR DI (1.8 MB per neighbour at 1080p), 96 B + 72 B for ReSTIR GI.  Every record is
 //                            then computed once, by its owner, with its full history: a static-camera sequence is bit-identical to the
 //                            single-GPU sequence on EVERY frame (tests/test_gpu_group.py), and Part 1 does 22 % less work at 8 bands.
 // Two transports under the same plan (`halo_plan`):
@@ -55,8 +55,8 @@ std::vector<XBuf> exchange_buffers(fyprt_context* c, int tech, int kind) {
         else v.push_back({c->dprevFlip ? (void*)c->dprevB.p : (void*)c->dprevA.p, sizeof(DIRec)});
     } else {
         if (kind == 0) {
-            v.push_back({c->gi.p, sizeof(GIRes)}); v.push_back({c->payload.p, sizeof(Payload)});
-            v.push_back({c->normalFlip ? (void*)c->normalA.p : (void*)c->normalB.p, sizeof(f2)});      // this frame's normals (normalCur)
+            v.push_back({c->gi.p, sizeof(GIRes)}); v.push_back({c->giHot.p, sizeof(float4)});            // Part 2 reads a neighbour's reservoir + hot record
+            v.push_back({c->normalFlip ? (void*)c->normalA.p : (void*)c->normalB.p, sizeof(f2)});      // this frame's normals: next frame's history normals
         } else v.push_back({c->giPrev.p, sizeof(GIRes)});          // (last frame's normals of the halo rows arrived with last frame's Part-1 exchange)
     }
     return v;

@@ -345,10 +345,11 @@ RT_DEV bool gi_update(GIRes& r, const GISample& s, float w, uint32_t count, floa
     if (rnd(seed) < w / r.wSum) { r.s = s; r.s.pdf = pdf; return true; }
     return false;
 }
-RT_DEV void gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {                                // :36-43
+RT_DEV bool gi_merge(GIRes& r, const GIRes& o, float pdf, uint32_t& seed) {                                // :36-43; true: r's sample was replaced
     const uint32_t prev = r.M;
-    gi_update(r, o.s, (pdf * o.wSum) * (float)o.M, 1u, pdf, seed);
+    const bool replaced = gi_update(r, o.s, (pdf * o.wSum) * (float)o.M, 1u, pdf, seed);
     r.M = prev + o.M;
+    return replaced;
 }
 RT_DEV f3 lo3(const GISample& s) { return mk3(s.Lo[0], s.Lo[1], s.Lo[2]); }
 

@@ -383,7 +383,8 @@ __global__ __launch_bounds__(kBlock) void k_gi_primary(DevScene sc, DevCamera ca
         const f3 pd = ray_direction(cam, x, y);
         const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, s_stack + threadIdx.x);
         fr.payload[i] = pp;
-        fr.normalCur[i] = oct_encode(nrm3(pp));
+        const f2 ncur = oct_encode(nrm3(pp));
+        fr.normalCur[i] = ncur;
         bool finished = false; f3 finalColor = splat3(0.0f);
         if (pp.hitDistance < 0.0f) { finished = true; finalColor = st.sky; }
         else {
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_gi_primary(DevScene sc, DevCamera ca
         if (finished) {
             GIRes R; gi_reset(R);
             fr.gi[i] = R; fr.depth[i] = pp.hitDistance;
+            fr.giHot[i] = make_float4(pp.hitDistance, ncur.x, ncur.y, 0.0f);       // an empty reservoir: |Lo| = 0
             if (inBand) epilogue(fr, i, rgb1(finalColor));
         } else live = true;
     }
@@ -489,16 +491,20 @@ RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         }
     }
     fr.gi[i] = R;
+    { const f2 n = oct_encode(nrm3(pp)); fr.giHot[i] = make_float4(pp.hitDistance, n.x, n.y, length(lo3(R.s))); }   // == payload.hitDistance, normalCur, |Lo| as Part 2 would compute them
     toPart2 = (y >= fr.rowBegin && y < fr.rowEnd);          // replaces the reference's image sentinel (R.cu:2746-2750 / :2787): Part 2 runs on a list
     return false;
 }
 
 // ============================================================ ReSTIR GI Part 2 (Renderer.cu:2295-2387): one visibility ray per accepted neighbour
 // state: S0..S4 = the reservoir being merged (18 floats), seed, neighbour counter | S5 = Z, neighbour pixel, its pdf
-RT_DEV void save_gires(float4* S, const GIRes& R, uint32_t seed, uint32_t n) {
-    S[0] = make_float4(R.s.vp[0], R.s.vp[1], R.s.vp[2], R.s.vn[0]);
-    S[1] = make_float4(R.s.vn[1], R.s.sp[0], R.s.sp[1], R.s.sp[2]);
-    S[2] = make_float4(R.s.sn[0], R.s.sn[1], R.s.Lo[0], R.s.Lo[1]);
+// (`sample` false: the reservoir's sample is what the state already holds — only the counters, the seed and pdf / W are rewritten)
+RT_DEV void save_gires(float4* S, const GIRes& R, uint32_t seed, uint32_t n, bool sample) {
+    if (sample) {
+        S[0] = make_float4(R.s.vp[0], R.s.vp[1], R.s.vp[2], R.s.vn[0]);
+        S[1] = make_float4(R.s.vn[1], R.s.sp[0], R.s.sp[1], R.s.sp[2]);
+        S[2] = make_float4(R.s.sn[0], R.s.sn[1], R.s.Lo[0], R.s.Lo[1]);
+    }
     S[3] = make_float4(R.s.Lo[2], __int_as_float((int)R.s.seed), R.s.pdf, R.W);
     S[4] = make_float4(__int_as_float((int)R.M), R.wSum, __int_as_float((int)seed), __int_as_float((int)n));
 }
@@ -515,6 +521,7 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     float4* S = io.state + (size_t)i * io.stateStride;
     const Payload pp = fr.payload[i];
     GIRes R; uint32_t seed, n = 0, Z = 0;
+    bool sampleChanged = true;                                              // the state record does not hold R's sample yet / any more
     if (io.iteration == 0u) {
         R = fr.gi[i];
         seed = i * (fr.frameIndex + 213u + st.randSeed);
@@ -527,16 +534,17 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         float pdf = s5.z;
         const GIRes N = fr.gi[ni];
         if (!(io.hitsIn[j].x != 0.0f)) pdf = 0.0f;                          // R.cu:2356-2366: the neighbour's sample point is not visible
-        gi_merge(R, N, pdf, seed);
+        sampleChanged = gi_merge(R, N, pdf, seed);
         ++n;
     }
     if (st.useSpatial) {
         for (; n < st.numNeighbors; ++n) {
             const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
-            const float nd = fr.payload[ni].hitDistance, pdp = pp.hitDistance;
-            const GIRes N = fr.gi[ni];
-            const float nlen = length(lo3(N.s));
-            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(fr.normalCur[ni])) < 0.906 || nlen == 0.0f) continue;
+            const float4 hot = fr.giHot[ni];                                 // depth, normal, |Lo| of the neighbour: one 16-byte gather decides
+            const float nd = hot.x, pdp = pp.hitDistance, nlen = hot.w;
+            f2 nnrm; nnrm.x = hot.y; nnrm.y = hot.z;
+            if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nnrm)) < 0.906 || nlen == 0.0f) continue;
+            const GIRes N = fr.gi[ni];                                       // accepted: now the 72-byte reservoir
             Z += N.M;
             f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
             const f3 sn = oct_decode(sne);
@@ -553,7 +561,7 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             const float pdf = jac > 0.0f ? nlen / jac : 0.0f;
             const float tol = gmax(1e-4f, distR * 1e-3f);
             out = ray_visible(nsp, dR, i, distR, tol);
-            save_gires(S, R, seed, n);
+            save_gires(S, R, seed, n, sampleChanged);
             S[5] = make_float4(__int_as_float((int)Z), __int_as_float((int)ni), pdf, 0.0f);
             return true;
         }

@@ -39,7 +39,7 @@ def main():
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
     st = capi.Settings(technique=a.technique, light_bounces=1 if a.technique == 7 else 2, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
-    per_px_bytes = {7: (32, 32), 8: (120, 72)}.get(a.technique, (0, 0))     # Part-1 records, history (fyprt_multi.h)
+    per_px_bytes = {7: (32, 32), 8: (96, 72)}.get(a.technique, (0, 0))     # Part-1 records, history (fyprt_multi.h)
 
     def time_band(y0, y1, halo):
         ctx.set_tuning(13, 0)

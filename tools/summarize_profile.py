@@ -18,7 +18,8 @@ sys.path.insert(0, str(ROOT))
 
 
 def kname(s):
-    return s.split("(")[0].replace("void ", "").replace("rt::", "").replace("<false>", "").strip()
+    import re
+    return re.sub(r"<[^>]*>", "", s.split("(")[0].replace("void ", "").replace("rt::", "")).strip()
 
 
 def main():
