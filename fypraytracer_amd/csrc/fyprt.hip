@@ -85,7 +85,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[15] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[16] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
@@ -706,7 +706,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
     else if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], fs));
     int launches = 0;
     // ---- wavefront path engine (rt_paths.h): primary kernel, then per step one shade launch + one persistent trace launch
-    struct StageRun { int stage; uint32_t steps, raysPer, stride; const uint32_t* pixelList; uint32_t* cnt; uint32_t* heads; uint32_t* part2List; uint32_t* part2Count; int counterPart; uint32_t* misCounts; };
+    struct StageRun { int stage; uint32_t steps, raysPer, stride; const uint32_t* pixelList; uint32_t* cnt; uint32_t* heads; uint32_t* part2List; uint32_t* part2Count; int counterPart; uint32_t* misCounts; size_t maxEntries; };
     auto run_stage = [&](const StageRun& r) -> int {
         const shade_kernel_t shade = shade_kernel(r.stage);
         const dim3 shadeGrid((uint32_t)(c->numCUs * 8));
@@ -737,7 +737,14 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
             q.rays = io.raysOut; q.hits = c->wfHits[(it + 1u) & 1u].p; q.count = io.countOut; q.raysPer = r.raysPer; q.head = r.heads + it + 1;
             q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24);
             q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
-            if (c->countRays) hipLaunchKernelGGL(k_trace_rays<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
+            // small trees (cheap rays): one thread per ray; big ones: persistent waves with lane refill (tuning key 15: 0 = by tree size)
+            const bool simple = c->tuning[15] == 2 || (c->tuning[15] == 0 && c->hostBvh.tris.size() < 65536u);
+            if (simple) {
+                const uint32_t sg = (uint32_t)std::min<size_t>((size_t)c->numCUs * 16u, (r.maxEntries * r.raysPer + kBlock - 1) / kBlock);
+                if (c->countRays) hipLaunchKernelGGL(k_trace_rays_simple<true>, dim3(std::max(1u, sg)), block, ldsBytes, c->stream, tsc, q);
+                else hipLaunchKernelGGL(k_trace_rays_simple<false>, dim3(std::max(1u, sg)), block, ldsBytes, c->stream, tsc, q);
+            }
+            else if (c->countRays) hipLaunchKernelGGL(k_trace_rays<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
             else hipLaunchKernelGGL(k_trace_rays<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
             if (r.steps > 8u && (it & 3u) == 3u) {                   // long sample x bounce products: stop once no path is alive any more
                 uint32_t alive = 0;
@@ -762,7 +769,7 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // coherent primary rays
             if (c->countRays) hipLaunchKernelGGL(k_primary<true>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
             else hipLaunchKernelGGL(k_primary<false>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
-            StageRun r{tech, steps, raysPer, stride, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, (tech == FYPRT_NEE) ? c->wfPixels2.p : nullptr, nullptr, 0, (tech == FYPRT_NEE) ? c->wfCounters.p + 2 * L : nullptr};
+            StageRun r{tech, steps, raysPer, stride, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, (tech == FYPRT_NEE) ? c->wfPixels2.p : nullptr, nullptr, 0, (tech == FYPRT_NEE) ? c->wfCounters.p + 2 * L : nullptr, entries};
             { const int rc = run_stage(r); if (rc != FYPRT_OK) return rc; }
             launches = 1;
             break;
@@ -791,12 +798,12 @@ static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, 
                     HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                     if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
                     else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                    StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr};
+                    StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
                     { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
                     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                     if (phase == 1) { c->part1Pending = true; return c->hip(hipGetLastError(), "ReSTIR GI part 1"); }
                 }
-                StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr};
+                StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr, p1px};
                 { const int rc = run_stage(r2); if (rc != FYPRT_OK) return rc; }
                 launches = 2;
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;
@@ -1030,17 +1037,17 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 15) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 16) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 15) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 16) return FYPRT_EINVAL;
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
-    static const int lo[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[15] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1, 1, 2};
+    static const int lo[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int hi[16] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1, 1, 2, 2};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

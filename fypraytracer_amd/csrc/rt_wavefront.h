@@ -566,6 +566,69 @@ RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_
     }
 }
 
+// The same ray records traced ONE THREAD PER RAY, no persistence: for scenes whose rays are cheap (a few node visits) the refill
+// machinery of the persistent kernel costs more than the divergence it removes (banana stand-in, 3 k triangles, 3 node visits per
+// ray: 130 us per launch persistent, see profiles/README.md r02).  Chosen by the host from the tree size (tuning key 15).
+template <bool COUNT>
+RT_DEV float4 trace_one(const DevScene& sc, f3 o, f3 d, uint32_t mode, float a0, float a1, int32_t* ldsBase) {
+    float tL = 3.402823466e+38f, hu = 0.0f, hv = 0.0f; int32_t hitTri = -1; bool closestMode = true;
+    if (mode == kRayVisible) { closestMode = false; hu = a0 - a1; tL = a0 + a1; }
+    else if (mode != kRayClosest && a0 > 0.0f) { closestMode = false; tL = a0; hitTri = (int32_t)mode; }
+    float cut = tL * 1.000001f;
+    uint32_t nBox = 0, nNode = 0, nTri = (mode != kRayClosest && mode != kRayVisible) ? 1u : 0u;
+    if (!(sc.triCount == 0 || ray_not_finite(o, d))) {
+        const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+        Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
+        int32_t cur = sc.rootRef;
+        bool done = false;
+        while (!done) {
+            while (cur >= 0) {
+                cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode);
+                if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+            }
+            if (cur >= 0) continue;
+            if (cur == kExit) break;
+            const uint32_t code = (uint32_t)~cur, firstTri = code >> 2, cnt = (code & 3u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4* tp = sc.leafTris + (size_t)(firstTri + k) * 3;
+                if (!closestMode && (uint32_t)__float_as_int(tp[2].y) == mode) continue;
+                float t, u, v; uint32_t id;
+                if (COUNT) nTri += 1;
+                if (!tri_test(tp, o, d, t, u, v, id)) continue;
+                if (mode == kRayVisible) {
+                    if (t < hu) { hv = -1.0f; done = true; break; }
+                    if (t <= tL) hv = 1.0f;
+                } else if (t < tL) {
+                    hitTri = (int32_t)id; tL = t;
+                    if (closestMode) { cut = t * 1.000001f; hu = u; hv = v; }
+                    else { done = true; break; }
+                }
+            }
+            cur = st.pop();
+        }
+    }
+    if (COUNT) {
+        atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox); atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri);
+        atomicAdd(sc.rayCounter + 3, (unsigned long long)((mode == kRayVisible) ? (hv > 0.0f ? 1 : 0) : (hitTri < 0 ? 0 : 1)));
+        atomicAdd(sc.rayCounter + 4, (unsigned long long)nNode);
+    }
+    if (mode == kRayVisible) return make_float4(hv > 0.0f ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+    return make_float4(hitTri < 0 ? -1.0f : tL, hu, hv, __int_as_float(hitTri));
+}
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_rays_simple(DevScene sc, TraceQueue q) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    const uint32_t total = *q.count * q.raysPer;
+    for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < total; base += gridDim.x * (uint32_t)kBlock) {   // (block-uniform trips: node_step's ballots see whole waves)
+        const uint32_t j = base + threadIdx.x;
+        if (j < total) {
+            const float4* t = q.rays + (size_t)j * 3;
+            const float4 t0 = t[0], t1 = t[1], t2 = t[2];
+            q.hits[j] = trace_one<COUNT>(sc, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), (uint32_t)__float_as_int(t1.w), t2.x, t2.y, s_stack + threadIdx.x);
+        }
+    }
+}
+
 template <bool COUNT> __global__ void k_trace_rays(DevScene sc, TraceQueue q);
 template <> __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void k_trace_rays<false>(DevScene sc, TraceQueue q) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch

@@ -277,7 +277,9 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        Default 0: measured slower (0.259 vs 0.225 ms) — register pressure and request rate outweigh the saved round trips.
  *        2 = the reservoir neighbourhood's hot fields (depth, normal; 12 B) of the workgroup's 76 x 76 pixel window staged in LDS (69 KB),
  *        the geometry test served from there; same results; measured slower as well (profiles/README.md r02).
- * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 12, 13: 0..1, key 14: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
+ * key 15: ray kernel of the wavefront stages (techniques 0-6, ReSTIR GI): 1 = persistent waves with lane refill, 2 = one thread per ray,
+ *        0 (default) = by tree size: one thread per ray below 65 536 triangles, where rays are too cheap for the refill machinery to pay.
+ * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 12, 13: 0..1, keys 14, 15: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
  * traversal must use too). */

@@ -19,6 +19,7 @@ VARIANTS = [
     {3: 1},                                         # shadow tasks sorted by light bin
     {6: 0}, {6: 40}, {7: 16},                       # node-loop quorum (shadow rays / every other kernel)
     {14: 1}, {14: 2},                               # Part-2 setup: speculative neighbour gathers / neighbourhood hot fields in LDS
+    {15: 1}, {15: 2},                               # wavefront stages' ray kernel: persistent / one thread per ray
 ]
 
 
@@ -139,7 +140,7 @@ def test_light_sorted_tasks_with_pipelined_async_frames():
 
 def test_tuning_values_are_range_checked():
     ctx = capi.Context(0)
-    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 0), (-1, 0)):
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 0), (-1, 0)):
         with pytest.raises(capi.FyprtError):
             ctx.set_tuning(key, bad)
     ctx.set_tuning(5, 64)

@@ -4,6 +4,7 @@ with exact ray counts from the device instrumentation.  Writes one JSON line per
 (Config 1 is the reference's CPU case — it is run on the GPU here too; config 5's 8-GPU split is bench.py's job:
 this tool reports its single-GPU 4K number.)"""
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -20,6 +21,9 @@ def run(name, sc, cam, W, H, st, frames=30, warm=5):
     ctx.resize(W, H)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
+    for kv in filter(None, os.environ.get("FYPRT_TUNING", "").split(",")):      # e.g. FYPRT_TUNING=15=2,6=16 (experiments)
+        k, v = kv.split("=")
+        ctx.set_tuning(int(k), int(v))
     for f in range(warm):
         st.rand_seed = f + 1
         ctx.render(st)
