@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import math
 
+from pathlib import Path
+
 import numpy as np
 
 from .scene import Camera, Material, Scene
@@ -324,13 +326,22 @@ def _stripe_texture(n=256):
     return ((255 << 24) | (b.astype(np.uint32) << 16) | (g.astype(np.uint32) << 8) | r.astype(np.uint32)).astype(np.uint32)
 
 
-def banana_scene(obj_path=None, png_path=None):
+BANANA_FIXTURE = Path(__file__).resolve().parent.parent / "tests" / "golden" / "banana_asset.npz"
+
+
+def banana_scene(obj_path=None, png_path=None, fixture="auto"):
     """BASELINE config 2: one ~3.2k-triangle mesh as a single BLAS, textured diffuse material, transform of
     WalnutApp.cpp:135-137 (pos (0,-3,0), rot (90,0,0)), a floor quad and one emissive quad above.
-    `obj_path` / `png_path` load the reference's own banana.obj / bananaDiffuse.png when available (never on the GPU
-    box); otherwise the procedural stand-in with the same triangle count and a procedural texture are used."""
+    Geometry + texture come from, in this order: `obj_path` / `png_path` (the reference's banana.obj / bananaDiffuse.png read in
+    place — build container only); the data fixture tests/golden/banana_asset.npz (the same assets ingested once by
+    tools/make_banana_fixture.py: what the GPU box uses); `fixture=None` or no fixture: a procedural stand-in (bent tube, stripe texture)."""
     sc = Scene()
-    if png_path is not None:
+    asset = None
+    if obj_path is None and png_path is None and fixture is not None and BANANA_FIXTURE.exists():
+        asset = np.load(BANANA_FIXTURE)
+    if asset is not None:
+        sc.textures = [asset["texture"]]
+    elif png_path is not None:
         from . import texture
         sc.textures = [texture.load_png(png_path)]                     # Texture::Texture (Texture.cu:8-40)
     else:
@@ -340,7 +351,9 @@ def banana_scene(obj_path=None, png_path=None):
         Material(albedo=(1, 1, 1), roughness=1.0, metallic=0.0),
         Material(albedo=(1, 1, 1), emission_color=(1, 1, 1), emission_power=40.0),
     ]
-    if obj_path is not None:
+    if asset is not None:
+        p, n, uv, idx = asset["positions"], asset["normals"], asset["uvs"], asset["indices"]
+    elif obj_path is not None:
         p, n, uv, idx = load_obj(obj_path)
     else:
         p, n, uv, idx = _bent_tube()

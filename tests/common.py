@@ -29,7 +29,8 @@ def struct_equal(a, b):
 SCENES = {
     "cornell": (lambda: scenes.cornell_box(), scenes.cornell_camera),
     "hall_small": (lambda: scenes.hall_scene_small(), scenes.hall_camera),
-    "banana": (lambda: scenes.banana_scene(), scenes.banana_camera),          # textured single-BLAS mesh (config 2 stand-in)
+    "banana": (lambda: scenes.banana_scene(), scenes.banana_camera),          # config 2: the reference's banana mesh + 2048x2048 texture (data fixture tests/golden/banana_asset.npz)
+    "banana_standin": (lambda: scenes.banana_scene(fixture=None), scenes.banana_camera),   # procedural stand-in of the same size
 }
 
 

@@ -58,7 +58,7 @@ def main():
     hall = scenes.hall_scene() if (not only or only & {"3", "4", "5"}) else None
     run("1 cornell 512x512 brute force 1spp 4 bounces", scenes.cornell_box(), scenes.cornell_camera(512, 512), 512, 512,
         capi.Settings(technique=capi.BRUTE_FORCE, light_bounces=4, sky_color=(0, 0, 0)))
-    run("2 banana-standin 1080p cosine 4spp 2 bounces", scenes.banana_scene(), scenes.banana_camera(1920, 1080), 1920, 1080,
+    run("2 banana (reference mesh + texture, data fixture) 1080p cosine 4spp 2 bounces" if scenes.BANANA_FIXTURE.exists() else "2 banana-standin 1080p cosine 4spp 2 bounces", scenes.banana_scene(), scenes.banana_camera(1920, 1080), 1920, 1080,
         capi.Settings(technique=capi.COSINE_WEIGHTED_SAMPLING, sample_count=4, light_bounces=2, sky_color=(0.3, 0.4, 0.5)))
     run("3 hall 1M 1080p NEE+MIS 1spp 2 bounces", hall, scenes.hall_camera(1920, 1080), 1920, 1080,
         capi.Settings(technique=capi.NEE, sample_count=1, light_bounces=2, sky_color=(0, 0, 0)))
