@@ -220,6 +220,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemsetAsync(c->di.p, 0, c->di.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->diPrev.p, 0, c->diPrev.bytes(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->gi.p, 0, c->gi.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->giPrev.p, 0, c->giPrev.bytes(), c->stream));
     HIPCHK(c, sync_all(c));
+    c->part1Pending = false;
     c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->externalImage = nullptr;
     c->histDI[0] = c->histGI[0] = 0; c->histDI[1] = c->histGI[1] = h;        // zero-filled history: "valid" everywhere, M = 0
     if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
@@ -638,7 +639,13 @@ static shade_kernel_t shade_kernel(int stage) {
 // phase: 0 = the whole frame; 1 = ReSTIR Part 1 only (nothing of the frame's bookkeeping advances); 2 = the rest of the frame that a
 // phase-1 call started.  The split exists for the halo EXCHANGE of a multi-GPU frame (fyprt_multi.h): Part 1 on every band, the
 // bands' Part-1 records of each other's halo rows copied across, Part 2 on every band.
+static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool timed, int phase);
 static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, int phase = 0) {
+    const int rc = enqueue_frame_impl(c, s, timed, phase);
+    if (rc != FYPRT_OK && rc != FYPRT_ESTATE) c->part1Pending = false;      // a frame that failed half-way is abandoned, not left pending
+    return rc;
+}
+static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool timed, int phase) {
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "host-only context (device -1) cannot render");
     if (!c->haveScene || !c->haveCamera || c->W == 0) return c->fail(FYPRT_ESTATE, "fyprt_render: resize, upload_scene and set_camera must precede render");
     if (c->dcam.W != c->W || c->dcam.H != c->H) return c->fail(FYPRT_ESTATE, "fyprt_render: camera viewport differs from the render size");

@@ -578,6 +578,8 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES
 #endif
+// (register budgets of the shade kernels are the compiler's own — 81 to 121 VGPRs, none spills; forcing 5 waves per SIMD spills in all
+// but three of them: tools/kernel_resources.py -DRT_SHADE_WAVES=...)
 template <int TECH>
 __global__ __launch_bounds__(kBlock) RT_SHADE_WAVES void k_shade(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, PathIO io) {
     const uint32_t count = *io.countIn;
