@@ -44,6 +44,7 @@ struct Builder {
     std::vector<Node2> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepthSafe;
     std::function<int32_t(const Prim*, uint32_t, uint32_t)> makeLeaf;   // (prims, count, depth) -> leaf ref
     static constexpr int kBins = 16;
+    float nodeCost = 1.0f;              // SAH: cost of visiting a node relative to testing a triangle (experiments: FYPRT_BVH_NODE_COST)
 
     int32_t build(Prim* p, uint32_t first, uint32_t last, uint32_t depth, Box& outBox) {
         const uint32_t count = last - first;
@@ -79,7 +80,7 @@ struct Builder {
         if (count <= maxLeaf && mustBalance) { maxDepth = std::max(maxDepth, depth); return makeLeaf(p + first, count, depth); }
         if (count <= maxLeaf) {
             const float leafCost = (float)count * nb.area();
-            const float splitCost = (bestAxis >= 0) ? 1.0f * nb.area() + bestCost : FLT_MAX;
+            const float splitCost = (bestAxis >= 0) ? nodeCost * nb.area() + bestCost : FLT_MAX;
             if (count == 1 || leafCost <= splitCost) { maxDepth = std::max(maxDepth, depth); return makeLeaf(p + first, count, depth); }
         }
         uint32_t mid;
@@ -206,6 +207,26 @@ struct Collapser {
     }
 };
 
+// Debug aid (FYPRT_BVH_DEBUG): the dynamic programme's objective — summed surface area of the wide nodes, proportional to the expected
+// number of node visits of a random ray — for a collapse into nodes of up to WIDTH children (what a wider node format would visit).
+template <int WIDTH> double collapseObjective(const std::vector<Node2>& bn, int32_t root) {
+    std::vector<std::array<float, WIDTH>> cost(bn.size());
+    std::function<void(int32_t)> solve = [&](int32_t ref) {
+        if (ref < 0) return;
+        const Node2& b = bn[ref];
+        solve(b.child0); solve(b.child1);
+        Box nb; nb.grow(b.lo0, b.hi0); nb.grow(b.lo1, b.hi1);
+        auto T = [&](int32_t r, int j) { return r < 0 ? 0.0f : cost[(size_t)r][j - 1]; };
+        float best[WIDTH + 1];
+        for (int j = 2; j <= WIDTH; ++j) { best[j] = FLT_MAX; for (int j0 = 1; j0 < j; ++j0) best[j] = std::min(best[j], T(b.child0, j0) + T(b.child1, j - j0)); }
+        auto& c = cost[(size_t)ref];
+        c[0] = nb.area() + best[WIDTH];
+        for (int j = 2; j <= WIDTH; ++j) c[j - 1] = std::min(c[j - 2], best[j]);
+    };
+    solve(root);
+    return root < 0 ? 0.0 : (double)cost[(size_t)root][0];
+}
+
 inline const uint32_t* triIdx(const uint8_t* tris, uint32_t stride, uint32_t i) { return reinterpret_cast<const uint32_t*>(tris + (size_t)i * stride); }
 
 }  // namespace
@@ -249,6 +270,7 @@ static void BuildWithDepthBound(const fyprt_vertex* verts, const uint8_t* tris, 
         }
         MeshOut& o = mo[m];
         Builder b; b.maxLeaf = 4; b.depthLimit = kMaxDepth - leafDepth[m];
+        if (const char* e = std::getenv("FYPRT_BVH_NODE_COST")) b.nodeCost = (float)std::atof(e);
         b.makeLeaf = [&](const Prim* p, uint32_t count, uint32_t) -> int32_t {
             const uint32_t first = (uint32_t)o.tris.size();
             for (uint32_t i = 0; i < count; ++i) {
@@ -299,6 +321,8 @@ static void BuildWithDepthBound(const fyprt_vertex* verts, const uint8_t* tris, 
     out.levels = levels;
     if (std::getenv("FYPRT_BVH_DEBUG")) { uint64_t f = tb.forced; uint32_t big = 0; for (uint32_t m = 0; m < meshCount; ++m) { f += mo[m].forced; big = std::max(big, meshes[m].triangle_count); } std::fprintf(stderr, "[bvh] forced median splits %llu, TLAS forced %llu, largest mesh %u tris\n", (unsigned long long)f, (unsigned long long)tb.forced, big); }
     if (std::getenv("FYPRT_BVH_DEBUG")) std::fprintf(stderr, "[bvh] binary nodes %zu height %u, wide nodes %zu, wide levels %u, tris %zu\n", bin.size(), col.h(binRoot), col.out.size(), levels, out.tris.size());
+    if (std::getenv("FYPRT_BVH_DEBUG")) std::fprintf(stderr, "[bvh] collapse objective (sum of wide-node areas ~ expected node visits): width 2 %.4g, 4 %.4g, 6 %.4g, 8 %.4g\n",
+                                                     collapseObjective<2>(bin, binRoot), collapseObjective<4>(bin, binRoot), collapseObjective<6>(bin, binRoot), collapseObjective<8>(bin, binRoot));
     out.nodes.swap(col.out);
 }
 

@@ -95,7 +95,7 @@ constexpr int kNcclChar = 0;      // ncclInt8 / ncclChar: transfers are counted 
 
 struct fyprt_group {
     std::vector<fyprt_context*> ctx; std::vector<uint32_t> bounds; int haloMode = 0;
-    std::vector<hipEvent_t> evP1, evPulled, evFrame; std::string err;
+    std::vector<hipEvent_t> evP1, evPulled, evFrame; hipEvent_t evGather = nullptr; bool gatherPending = false; std::string err;
 };
 
 int fyprt_group_synchronize(fyprt_group* g);
@@ -119,6 +119,8 @@ int fyprt_group_create(fyprt_context** ctxs, int n, const uint32_t* row_bounds, 
         (void)hipEventCreateWithFlags(&g->evP1[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&g->evPulled[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&g->evFrame[i], hipEventDisableTiming);
     }
+    (void)hipSetDevice(ctxs[0]->device);
+    (void)hipEventCreateWithFlags(&g->evGather, hipEventDisableTiming);
     *out = g;
     return FYPRT_OK;
 }
@@ -129,6 +131,7 @@ void fyprt_group_destroy(fyprt_group* g) {
         (void)hipEventDestroy(g->evP1[i]); (void)hipEventDestroy(g->evPulled[i]); (void)hipEventDestroy(g->evFrame[i]);
         g->ctx[i]->haloExchange = false;
     }
+    if (g->evGather) (void)hipEventDestroy(g->evGather);
     delete g;
 }
 // New band boundaries (e.g. from fyprt_balance_rows).  Rows that change owner take their accumulation and their temporal history
@@ -177,7 +180,10 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
     for (int i = 0; i < n; ++i) {
         fyprt_context* c = g->ctx[i];
         c->rowBegin = g->bounds[i]; c->rowEnd = g->bounds[i + 1]; c->halo = halo; c->rowsSet = true; c->haloExchange = exchange;
+        // the previous frame's gather still reads this band's image rows on the root's stream: the new frame's epilogues wait for it
+        if (g->gatherPending) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamWaitEvent(c->stream, g->evGather, 0)); }
     }
+    g->gatherPending = false;
     if (!exchange) {
         for (int i = 0; i < n; ++i) {
             fyprt_context* c = g->ctx[i];
@@ -244,6 +250,8 @@ int fyprt_group_gather(fyprt_group* g, int root) {
         const size_t off = (size_t)g->bounds[i] * r->W, cnt = (size_t)(g->bounds[i + 1] - g->bounds[i]) * r->W;
         HIPCHK(r, hipMemcpyPeerAsync(dst + off, r->device, src + off, c->device, cnt * 4, r->stream));
     }
+    HIPCHK(r, hipEventRecord(g->evGather, r->stream));
+    g->gatherPending = true;
     return FYPRT_OK;
 }
 int fyprt_group_synchronize(fyprt_group* g) {

@@ -69,3 +69,58 @@ def test_full_frame_reference_vs_product_order(oracle_built):
     same = ((outs[0] == outs[1]) | (np.isnan(outs[0]) & np.isnan(outs[1]))).all(-1)
     assert same.mean() >= 0.999
     ctx.close()
+
+
+def _brute_force_closest(sc, origins, dirs):
+    """Closest hit by testing EVERY triangle — numpy float32, the reference's Möller–Trumbore operation order (Renderer.cu:513-537):
+    no acceleration structure, no code shared with either tracer.  Returns the closest t per ray (-1: miss)."""
+    F = np.float32
+    pos = sc.world_vertices["position"].astype(F)
+    t = sc.triangles
+    v0, v1, v2 = pos[t["v0"]], pos[t["v1"]], pos[t["v2"]]
+    e1, e2 = (v1 - v0).astype(F), (v2 - v0).astype(F)
+
+    def cross(a, b):
+        return np.stack([a[..., 1] * b[..., 2] - b[..., 1] * a[..., 2], a[..., 2] * b[..., 0] - b[..., 2] * a[..., 0], a[..., 0] * b[..., 1] - b[..., 0] * a[..., 1]], -1).astype(F)
+
+    def dot(a, b):
+        return ((a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]).astype(F)
+    out = np.full(len(origins), -1.0, dtype=F)
+    with np.errstate(all="ignore"):
+        for i, (o, d) in enumerate(zip(origins, dirs)):
+            h = cross(np.broadcast_to(d, e2.shape), e2)
+            f = (F(1.0) / dot(e1, h)).astype(F)
+            s = (o[None, :] - v0).astype(F)
+            u = (f * dot(s, h)).astype(F)
+            q = cross(s, e1)
+            v = (f * dot(np.broadcast_to(d, q.shape), q)).astype(F)
+            tt = (f * dot(e2, q)).astype(F)
+            ok = ~((u < 0) | (u > 1)) & ~((v < 0) | ((u + v).astype(F) > 1)) & (tt > F(0.0001))
+            if ok.any():
+                out[i] = tt[ok].min()
+    return out
+
+
+@pytest.mark.parametrize("name", ["hall_small", "cornell"])
+def test_both_tracers_find_the_brute_force_closest_hit(oracle_built, name):
+    """An independent pin of the oracle's two traversals (and, through the bit-exact GPU tests, of the HIP traversal): neither the
+    reference-order TLAS/BLAS walk nor the product's quantised 4-wide walk may miss the triangle an exhaustive test finds — the hit
+    DISTANCE must agree bit for bit (which of two triangles at exactly that distance is reported is the tie freedom of DESIGN.md §5)."""
+    sc = scenes.cornell_box() if name == "cornell" else scenes.hall_scene_small()
+    ctx = capi.Context(-1)
+    ctx.upload_scene(sc)
+    o = Oracle(sc, 8, 8)
+    rng = np.random.default_rng(7)
+    lo, hi = sc.world_vertices["position"].min(0), sc.world_vertices["position"].max(0)
+    n = 600
+    origins = rng.uniform(lo + 0.05 * (hi - lo), hi - 0.05 * (hi - lo), (n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3))
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    want = _brute_force_closest(sc, origins, dirs)
+    for product in (False, True):
+        if product:
+            o.use_product_bvh(ctx.export_bvh())
+        got = np.array([o.trace(origins[i], dirs[i])[0]["hitDistance"] for i in range(n)], dtype=np.float32)
+        assert np.array_equal(got, want), (product, int((got != want).sum()))
+    assert (want > 0).mean() > 0.7
+    ctx.close()
