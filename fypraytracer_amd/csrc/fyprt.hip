@@ -733,6 +733,9 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
             io.iteration = it; io.raysPer = r.raysPer; io.part2List = r.part2List; io.part2Count = r.part2Count;
             // NEE's MIS list reuses the primary kernel's pixel list, which only step 0 reads (and step 0 has no ray results, hence no MIS entries)
             io.misList = c->wfPixels.p; io.misCount = r.misCounts ? r.misCounts + it : nullptr;
+            if (r.stage == T_GI2) {                                  // owner lists ping-pong between the Part-2 list's buffer and the (by now free) primary list's
+                io.ownersIn = (it & 1u) ? c->wfPixels.p : c->wfPixels2.p; io.ownersOut = (it & 1u) ? c->wfPixels2.p : c->wfPixels.p;
+            }
             hipLaunchKernelGGL(shade, shadeGrid, block, 0, c->stream, c->dsc, c->dcam, fr, st, io);
             if (r.stage == T_NEE && it > 0u)                         // NEE: emitter-hit MIS for the few paths that need it (may add to the pick list)
                 hipLaunchKernelGGL(k_nee_mis, dim3((uint32_t)c->numCUs), block, 0, c->stream, c->dsc, c->dcam, fr, st, (const uint32_t*)io.misList, (const uint32_t*)io.misCount,
@@ -799,18 +802,18 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                 const size_t p1px = ((size_t)(p1e - p1b) + (extra ? 1u : 0u)) * c->W;
                 const uint32_t steps1 = st.maxBounces, steps2 = st.useSpatial ? st.numNeighbors : 0u;
                 const size_t L1 = (size_t)steps1 + 2, L2 = (size_t)steps2 + 2;
-                { const int rc = ensure_paths(c, p1px, 1, 6, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
+                { const int rc = ensure_paths(c, p1px, 1, 4, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
                 uint32_t* cnt1 = c->wfCounters.p; uint32_t* cnt2 = cnt1 + 2 * L1;      // cnt2[0] = length of the Part-2 list
                 if (phase != 2) {
                     HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                     if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
                     else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                    StageRun r1{T_GI1, steps1, 1u, 6u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
+                    StageRun r1{T_GI1, steps1, 1u, 4u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
                     { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
                     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                     if (phase == 1) { c->part1Pending = true; return c->hip(hipGetLastError(), "ReSTIR GI part 1"); }
                 }
-                StageRun r2{T_GI2, steps2, 1u, 6u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr, p1px};
+                StageRun r2{T_GI2, steps2, 1u, 4u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr, p1px};
                 { const int rc = run_stage(r2); if (rc != FYPRT_OK) return rc; }
                 launches = 2;
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;
@@ -982,6 +985,15 @@ int fyprt_read_buffer(fyprt_context* c, int which, void* dst, size_t bytes) {
         case FYPRT_BUF_GI_RESERVOIR: src = c->gi.p; n = c->gi.bytes(); break;
         case FYPRT_BUF_GI_PREV: src = c->giPrev.p; n = c->giPrev.bytes(); break;
         default: return c->fail(FYPRT_EINVAL, "fyprt_read_buffer: unknown buffer");
+    }
+    if (which == FYPRT_BUF_GI_RESERVOIR || which == FYPRT_BUF_GI_PREV) {
+        // the device keeps the 72-byte reservoirs padded to 80 aligned bytes (rt_device.h): hand out the reference layout
+        const size_t npx = (size_t)c->W * c->H;
+        std::vector<GIRes> rec(npx);
+        HIPCHK(c, hipMemcpy(rec.data(), src, npx * sizeof(GIRes), hipMemcpyDeviceToHost));
+        const size_t cnt = std::min(npx, bytes / kGIResBytes);
+        for (size_t p = 0; p < cnt; ++p) std::memcpy((char*)dst + p * kGIResBytes, &rec[p], kGIResBytes);
+        return FYPRT_OK;
     }
     if (c->lastTech == FYPRT_RESTIR_DI && (which == FYPRT_BUF_NORMAL || which == FYPRT_BUF_DI_RESERVOIR || which == FYPRT_BUF_DI_PREV)) {
         // ReSTIR DI keeps normal + reservoir packed in 32-byte records (DIRec); unpack into the reference layouts

@@ -36,8 +36,12 @@ struct DevCamera { m4 invProj, invView, prevProjView; f3 position; uint32_t W, H
 struct Payload { float hitDistance; float px, py, pz; float nx, ny, nz; float u, v; int32_t objectIndex; };   // Ray.h:13-22 (40 B)
 struct DIRes { uint32_t index; float W, pdf, wSum; uint32_t M; };                                             // 20 B
 struct GISample { float vp[3]; float vn[2]; float sp[3]; float sn[2]; float Lo[3]; uint32_t seed; float pdf; };
-struct GIRes { GISample s; float W; uint32_t M; float wSum; };                                                // 72 B
-static_assert(sizeof(Payload) == 40 && sizeof(DIRes) == 20 && sizeof(GIRes) == 72, "layout");
+// The reference's ReSTIR_GI_Reservoir is 72 bytes (8-byte aligned: a record is nine dwordx2 loads and straddles cache lines).  On the
+// device it is padded to 80 bytes and aligned to 16: five dwordx4 loads per record — Part 2 gathers two of them per neighbour step.
+// fyprt_read_buffer hands out the reference's 72-byte layout.
+struct alignas(16) GIRes { GISample s; float W; uint32_t M; float wSum; float pad[2]; };
+constexpr size_t kGIResBytes = 72;
+static_assert(sizeof(Payload) == 40 && sizeof(DIRes) == 20 && sizeof(GIRes) == 80 && sizeof(GISample) == 60, "layout");
 
 // ReSTIR DI per-pixel record: everything a *neighbour* (spatial reuse) or the *next frame* (temporal reuse) reads
 // about a pixel, packed into one aligned 32-byte line half — primary hit distance, octahedral normal, reservoir —

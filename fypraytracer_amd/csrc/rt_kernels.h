@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
 
 // ============================================================ ReSTIR GI (Renderer.cu:2043-2387)
 RT_DEV void gi_reset_sample(GISample& s) { s.vp[0] = s.vp[1] = s.vp[2] = 0.0f; s.vn[0] = s.vn[1] = 0.0f; s.sp[0] = s.sp[1] = s.sp[2] = 0.0f; s.sn[0] = s.sn[1] = 0.0f; s.Lo[0] = s.Lo[1] = s.Lo[2] = 0.0f; s.seed = 0; s.pdf = 0.0f; }
-RT_DEV void gi_reset(GIRes& r) { gi_reset_sample(r.s); r.W = 0.0f; r.M = 0; r.wSum = 0.0f; }
+RT_DEV void gi_reset(GIRes& r) { gi_reset_sample(r.s); r.W = 0.0f; r.M = 0; r.wSum = 0.0f; r.pad[0] = r.pad[1] = 0.0f; }
 RT_DEV bool gi_update(GIRes& r, const GISample& s, float w, uint32_t count, float pdf, uint32_t& seed) {   // ReSTIR_GI_Reservoir.cu:5-34
     r.wSum += w; r.M += count;
     if (rnd(seed) < w / r.wSum) { r.s = s; r.s.pdf = pdf; return true; }

@@ -32,6 +32,7 @@ struct PathIO {
     uint32_t iteration, raysPer;                                              // rays per entry (2 for NEE with more than one bounce)
     uint32_t* part2List; uint32_t* part2Count;                                // ReSTIR GI: pixels that continue into Part 2; NEE: the PICK list (counter = countOut)
     uint32_t* misList; uint32_t* misCount;                                    // NEE: paths whose BRDF ray hit an emitter
+    const uint32_t* ownersIn; uint32_t* ownersOut;                            // ReSTIR GI Part 2: the entries' pixels as a list of their own (its steps do not read the ray records)
 };
 
 struct RayRec { float4 q0, q1, q2; };
@@ -402,18 +403,18 @@ __global__ __launch_bounds__(kBlock) void k_gi_primary(DevScene sc, DevCamera ca
     if (live) pixelList[slot] = i;
 }
 
-// state: S0 = throughput, seed | S1 = Lo, bounce | S2 = sample point, original seed | S3 = sample normal
+// state: S0 = throughput, seed | S1 = Lo, bounce | S2 = sample point | S3 = sample normal   (S2 / S3 are written by the step that sees the
+// first bounce's hit and read by the step that finishes the path only: the steps are HBM-bound, every quad not moved counts)
 // returns true while the bounce path needs another ray; `toPart2` = the pixel's reservoir is final and the pixel is inside the band
 RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out, bool& toPart2) {
     const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
     float4* S = io.state + (size_t)i * io.stateStride;
-    const Payload pp = fr.payload[i];
-    uint32_t seed, originalSeed; int b = 0;
+    uint32_t seed; int b = 0;
     f3 T = splat3(1.0f), Lo = splat3(0.0f), samplePoint = splat3(0.0f), sampleNormal = splat3(0.0f), ro, rd;
-    bool open;
+    bool open, haveSample = true;                                          // haveSample: samplePoint / sampleNormal are in registers (not only in S2 / S3)
     if (io.iteration == 0u) {
+        const Payload pp = fr.payload[i];
         seed = i * (fr.frameIndex + 1u + st.randSeed);
-        originalSeed = seed;
         const f3 pd = ray_direction(cam, x, y);
         const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
         const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
@@ -425,14 +426,14 @@ RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
         open = st.maxBounces > 0u;
     } else {
-        const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
+        const float4 s0 = S[0], s1 = S[1];
         T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); Lo = xyz(s1); b = __float_as_int(s1.w);
-        samplePoint = xyz(s2); originalSeed = (uint32_t)__float_as_int(s2.w); sampleNormal = xyz(s3);
         const float4* R = io.raysIn + (size_t)j * 3;
         ro = xyz(R[0]); rd = xyz(R[1]);
         const Hit h = load_hit(io.hitsIn, j);
         const Payload hit = (h.tri < 0) ? make_miss() : make_hit(sc, ro, rd, h);
         if (b == 0) { samplePoint = pos3(hit); sampleNormal = nrm3(hit); }
+        else haveSample = false;
         open = false;
         if (hit.hitDistance < 0.0f) Lo = Lo + T * st.sky;
         else {
@@ -454,12 +455,16 @@ RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     }
     toPart2 = false;
     if (open) {
+        if (io.iteration != 0u && b == 1) { S[2] = f3f(samplePoint, 0.0f); S[3] = f3f(sampleNormal, 0.0f); }      // (b was 0 when this step started)
         seed += (uint32_t)(31 * b);
         out = ray_closest(ro, rd, i);
-        S[0] = f3w(T, seed); S[1] = f3w(Lo, (uint32_t)b); S[2] = f3w(samplePoint, originalSeed); S[3] = f3f(sampleNormal, 0.0f);
+        S[0] = f3w(T, seed); S[1] = f3w(Lo, (uint32_t)b);
         return true;
     }
     // the path is complete: initial reservoir (R.cu:2186-2228), temporal reuse (:2230-2290)
+    if (!haveSample) { samplePoint = xyz(S[2]); sampleNormal = xyz(S[3]); }
+    const Payload pp = fr.payload[i];
+    const uint32_t originalSeed = i * (fr.frameIndex + 1u + st.randSeed);  // the seed the path started from (R.cu:2094)
     GIRes R; gi_reset(R);
     {
         GISample sm; sm.seed = originalSeed;
@@ -497,59 +502,52 @@ RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 }
 
 // ============================================================ ReSTIR GI Part 2 (Renderer.cu:2295-2387): one visibility ray per accepted neighbour
-// state: S0..S4 = the reservoir being merged (18 floats), seed, neighbour counter | S5 = Z, neighbour pixel, its pdf
-// (`sample` false: the reservoir's sample is what the state already holds — only the counters, the seed and pdf / W are rewritten)
-RT_DEV void save_gires(float4* S, const GIRes& R, uint32_t seed, uint32_t n, bool sample) {
-    if (sample) {
-        S[0] = make_float4(R.s.vp[0], R.s.vp[1], R.s.vp[2], R.s.vn[0]);
-        S[1] = make_float4(R.s.vn[1], R.s.sp[0], R.s.sp[1], R.s.sp[2]);
-        S[2] = make_float4(R.s.sn[0], R.s.sn[1], R.s.Lo[0], R.s.Lo[1]);
-    }
-    S[3] = make_float4(R.s.Lo[2], __int_as_float((int)R.s.seed), R.s.pdf, R.W);
-    S[4] = make_float4(__int_as_float((int)R.M), R.wSum, __int_as_float((int)seed), __int_as_float((int)n));
-}
-RT_DEV void load_gires(const float4* S, GIRes& R, uint32_t& seed, uint32_t& n) {
-    const float4 a = S[0], b = S[1], c = S[2], d = S[3], e = S[4];
-    R.s.vp[0] = a.x; R.s.vp[1] = a.y; R.s.vp[2] = a.z; R.s.vn[0] = a.w;
-    R.s.vn[1] = b.x; R.s.sp[0] = b.y; R.s.sp[1] = b.z; R.s.sp[2] = b.w;
-    R.s.sn[0] = c.x; R.s.sn[1] = c.y; R.s.Lo[0] = c.z; R.s.Lo[1] = c.w;
-    R.s.Lo[2] = d.x; R.s.seed = (uint32_t)__float_as_int(d.y); R.s.pdf = d.z; R.W = d.w;
-    R.M = (uint32_t)__float_as_int(e.x); R.wSum = e.y; seed = (uint32_t)__float_as_int(e.z); n = (uint32_t)__float_as_int(e.w);
-}
+// The steps are HBM-bound (0.56 L2 hit rate, 5.7 TB/s), so the state between two steps is as small as the algorithm allows: the
+// reservoir's sample is always SOME pixel's Part-1 sample (its own, or the neighbour's that a merge selected) with only `pdf` replaced
+// (ReSTIR_GI_Reservoir.cu:5-34), and Part 1's reservoirs do not change during Part 2 — so the state names that pixel instead of carrying
+// the 60-byte sample; and a merge needs nothing of the neighbour but its weightSum and M, which are kept from the step that emitted the
+// visibility ray (no second gather of the neighbour's reservoir).
+// state: S0 = sample's source pixel, sample pdf, W, weightSum | S1 = M, seed, neighbour counter, Z | S2 = pending neighbour: pixel, pdf, its weightSum, its M
 RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
-    const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
+    const uint32_t i = io.ownersIn[j], x = i % fr.W, y = i / fr.W;
     float4* S = io.state + (size_t)i * io.stateStride;
     const Payload pp = fr.payload[i];
-    GIRes R; uint32_t seed, n = 0, Z = 0;
-    bool sampleChanged = true;                                              // the state record does not hold R's sample yet / any more
+    uint32_t src, seed, n = 0, Z = 0, M; float spdf, Wr, wSum;
     if (io.iteration == 0u) {
-        R = fr.gi[i];
+        const GIRes own = fr.gi[i];
+        src = i; spdf = own.s.pdf; Wr = own.W; wSum = own.wSum; M = own.M;
         seed = i * (fr.frameIndex + 213u + st.randSeed);
-        if (st.useSpatial) { const float plen = length(lo3(R.s)); Z = plen > 0.0f ? R.M : 0u; }
+        if (st.useSpatial) { const float plen = length(lo3(own.s)); Z = plen > 0.0f ? M : 0u; }
     } else {
-        load_gires(S, R, seed, n);
-        const float4 s5 = S[5];
-        Z = (uint32_t)__float_as_int(s5.x);
-        const uint32_t ni = (uint32_t)__float_as_int(s5.y);
-        float pdf = s5.z;
-        const GIRes N = fr.gi[ni];
+        const float4 s0 = S[0], s1 = S[1], s2 = S[2];
+        src = (uint32_t)__float_as_int(s0.x); spdf = s0.y; Wr = s0.z; wSum = s0.w;
+        M = (uint32_t)__float_as_int(s1.x); seed = (uint32_t)__float_as_int(s1.y); n = (uint32_t)__float_as_int(s1.z); Z = (uint32_t)__float_as_int(s1.w);
+        const uint32_t ni = (uint32_t)__float_as_int(s2.x);
+        float pdf = s2.y;
+        const float nWSum = s2.z; const uint32_t nM = (uint32_t)__float_as_int(s2.w);
         if (!(io.hitsIn[j].x != 0.0f)) pdf = 0.0f;                          // R.cu:2356-2366: the neighbour's sample point is not visible
-        sampleChanged = gi_merge(R, N, pdf, seed);
+        // gi_merge(R, N, pdf, seed) on the counters (ReSTIR_GI_Reservoir.cu:36-43 -> :5-34)
+        const uint32_t prevM = M;
+        const float w = (pdf * nWSum) * (float)nM;
+        wSum += w; M += 1u;
+        if (rnd(seed) < w / wSum) { src = ni; spdf = pdf; }
+        M = prevM + nM;
         ++n;
     }
     if (st.useSpatial) {
+        f3 rvp = splat3(0.0f); bool haveVp = false;
         for (; n < st.numNeighbors; ++n) {
             const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
             const float4 hot = fr.giHot[ni];                                 // depth, normal, |Lo| of the neighbour: one 16-byte gather decides
             const float nd = hot.x, pdp = pp.hitDistance, nlen = hot.w;
             f2 nnrm; nnrm.x = hot.y; nnrm.y = hot.z;
             if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nnrm)) < 0.906 || nlen == 0.0f) continue;
-            const GIRes N = fr.gi[ni];                                       // accepted: now the 72-byte reservoir
+            const GIRes N = fr.gi[ni];                                       // accepted: now the reservoir
             Z += N.M;
+            if (!haveVp) { const GIRes Rs = fr.gi[src]; rvp = mk3(Rs.s.vp[0], Rs.s.vp[1], Rs.s.vp[2]); haveVp = true; }      // the current sample's visible point
             f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
             const f3 sn = oct_decode(sne);
             const f3 nvp = mk3(N.s.vp[0], N.s.vp[1], N.s.vp[2]), nsp = mk3(N.s.sp[0], N.s.sp[1], N.s.sp[2]);
-            const f3 rvp = mk3(R.s.vp[0], R.s.vp[1], R.s.vp[2]);
             const f3 dQ = normalize(nvp - nsp);
             const float cosQ = dot(sn, dQ);
             const f3 dR = normalize(rvp - nsp);
@@ -561,12 +559,15 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             const float pdf = jac > 0.0f ? nlen / jac : 0.0f;
             const float tol = gmax(1e-4f, distR * 1e-3f);
             out = ray_visible(nsp, dR, i, distR, tol);
-            save_gires(S, R, seed, n, sampleChanged);
-            S[5] = make_float4(__int_as_float((int)Z), __int_as_float((int)ni), pdf, 0.0f);
+            S[0] = make_float4(__int_as_float((int)src), spdf, Wr, wSum);
+            S[1] = make_float4(__int_as_float((int)M), __int_as_float((int)seed), __int_as_float((int)n), __int_as_float((int)Z));
+            S[2] = make_float4(__int_as_float((int)ni), pdf, N.wSum, __int_as_float((int)N.M));
             return true;
         }
-        R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;
     }
+    GIRes R = fr.gi[src];                                                   // the selected sample, with the reservoir's own pdf / counters
+    R.s.pdf = spdf; R.M = M; R.wSum = wSum; R.W = Wr;
+    if (st.useSpatial) R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;
     const f3 radiance = lo3(R.s) * R.W;
     fr.depth[i] = pp.hitDistance;
     fr.giPrev[i] = R;
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(kBlock) RT_SHADE_WAVES void k_shade(DevScene sc, De
         if (live) {
             if (TECH == T_NEE) io.part2List[slot] = owner;             // NEE: the rays are built by k_nee_emit from this list
             else store_ray(io.raysOut, slot * io.raysPer, r0);
+            if (TECH == T_GI2) io.ownersOut[slot] = io.ownersIn[j];
         }
         if (TECH == T_GI1) {
             const uint32_t slot2 = block_append(toPart2, io.part2Count);

@@ -149,3 +149,27 @@ def test_rccl_communicator_of_one_rank():
     assert np.array_equal(img, ref[0]) and bits_equal(acc, ref[1]).all()
     lib.fyprt_comm_destroy(ctx.h)
     ctx.close()
+
+
+def test_asynchronous_frames_with_a_gather_per_frame():
+    """No synchronisation between frames: the next frame's epilogues must not overwrite a band the root's gather is still copying, the
+    halo pulls of frame N+1 must not overtake frame N.  The frame gathered at the end is the single-context frame."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 320, 192
+    cam = mk_cam(W, H)
+    frames, bounds = 12, [0, 50, 120, 192]
+    ref = _single(sc, cam, W, H, capi.RESTIR_DI, frames)[-1]
+    ctxs = _contexts(3, sc, cam, W, H)
+    grp = capi.Group(ctxs, bounds, halo_mode=1)
+    st = settings_for(capi.RESTIR_DI)
+    for f in range(frames):
+        st.rand_seed = f + 1
+        grp.render(st)
+        grp.gather(1)                                        # the middle band's context presents
+    grp.synchronize()
+    ctxs[1].set_rows(0, H, 0)
+    full, _ = ctxs[1].readback(want_accum=False)
+    assert np.array_equal(full, ref[0])
+    grp.close()
+    for c in ctxs:
+        c.close()

@@ -8,7 +8,9 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 : > "$OUT/${TAG}_pmc.csv"
-for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU" "GRBM_GUI_ACTIVE SQ_WAVES"; do
+# counter sets, one pass each; override with PMC_SETS="A B;C;D E" (';' separates passes)
+IFS=';' read -r -a SETS <<< "${PMC_SETS:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU;SQ_WAVE_CYCLES SQ_WAIT_ANY;SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU;GRBM_GUI_ACTIVE SQ_WAVES}"
+for set in "${SETS[@]}"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/${TAG}_$tag" -- python3 "$R/tools/bench_configs.py" "$@" > /dev/null 2> "$OUT/${TAG}_$tag.err" || echo "pass $tag failed"
   f=$(find "$OUT/${TAG}_$tag" -name '*counter_collection.csv' | head -1)
