@@ -802,18 +802,18 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                 const size_t p1px = ((size_t)(p1e - p1b) + (extra ? 1u : 0u)) * c->W;
                 const uint32_t steps1 = st.maxBounces, steps2 = st.useSpatial ? st.numNeighbors : 0u;
                 const size_t L1 = (size_t)steps1 + 2, L2 = (size_t)steps2 + 2;
-                { const int rc = ensure_paths(c, p1px, 1, 4, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
+                { const int rc = ensure_paths(c, p1px, 1, 5, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
                 uint32_t* cnt1 = c->wfCounters.p; uint32_t* cnt2 = cnt1 + 2 * L1;      // cnt2[0] = length of the Part-2 list
                 if (phase != 2) {
                     HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                     if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
                     else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                    StageRun r1{T_GI1, steps1, 1u, 4u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
+                    StageRun r1{T_GI1, steps1, 1u, 5u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
                     { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
                     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                     if (phase == 1) { c->part1Pending = true; return c->hip(hipGetLastError(), "ReSTIR GI part 1"); }
                 }
-                StageRun r2{T_GI2, steps2, 1u, 4u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr, p1px};
+                StageRun r2{T_GI2, steps2, 1u, 5u, c->wfPixels2.p, cnt2, cnt2 + L2, nullptr, nullptr, 1, nullptr, p1px};
                 { const int rc = run_stage(r2); if (rc != FYPRT_OK) return rc; }
                 launches = 2;
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;

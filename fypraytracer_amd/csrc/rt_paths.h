@@ -508,14 +508,15 @@ RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 // the 60-byte sample; and a merge needs nothing of the neighbour but its weightSum and M, which are kept from the step that emitted the
 // visibility ray (no second gather of the neighbour's reservoir).
 // state: S0 = sample's source pixel, sample pdf, W, weightSum | S1 = M, seed, neighbour counter, Z | S2 = pending neighbour: pixel, pdf, its weightSum, its M
+//        S3 = the current sample's visible point (the only part of the sample a step needs) | S4 = the pending neighbour's visible point
 RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
     const uint32_t i = io.ownersIn[j], x = i % fr.W, y = i / fr.W;
     float4* S = io.state + (size_t)i * io.stateStride;
     const Payload pp = fr.payload[i];
-    uint32_t src, seed, n = 0, Z = 0, M; float spdf, Wr, wSum;
+    uint32_t src, seed, n = 0, Z = 0, M; float spdf, Wr, wSum; f3 rvp; bool rvpChanged = true;
     if (io.iteration == 0u) {
         const GIRes own = fr.gi[i];
-        src = i; spdf = own.s.pdf; Wr = own.W; wSum = own.wSum; M = own.M;
+        src = i; spdf = own.s.pdf; Wr = own.W; wSum = own.wSum; M = own.M; rvp = mk3(own.s.vp[0], own.s.vp[1], own.s.vp[2]);
         seed = i * (fr.frameIndex + 213u + st.randSeed);
         if (st.useSpatial) { const float plen = length(lo3(own.s)); Z = plen > 0.0f ? M : 0u; }
     } else {
@@ -525,17 +526,17 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         const uint32_t ni = (uint32_t)__float_as_int(s2.x);
         float pdf = s2.y;
         const float nWSum = s2.z; const uint32_t nM = (uint32_t)__float_as_int(s2.w);
+        rvp = xyz(S[3]); rvpChanged = false;
         if (!(io.hitsIn[j].x != 0.0f)) pdf = 0.0f;                          // R.cu:2356-2366: the neighbour's sample point is not visible
         // gi_merge(R, N, pdf, seed) on the counters (ReSTIR_GI_Reservoir.cu:36-43 -> :5-34)
         const uint32_t prevM = M;
         const float w = (pdf * nWSum) * (float)nM;
         wSum += w; M += 1u;
-        if (rnd(seed) < w / wSum) { src = ni; spdf = pdf; }
+        if (rnd(seed) < w / wSum) { src = ni; spdf = pdf; rvp = xyz(S[4]); rvpChanged = true; }
         M = prevM + nM;
         ++n;
     }
     if (st.useSpatial) {
-        f3 rvp = splat3(0.0f); bool haveVp = false;
         for (; n < st.numNeighbors; ++n) {
             const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
             const float4 hot = fr.giHot[ni];                                 // depth, normal, |Lo| of the neighbour: one 16-byte gather decides
@@ -544,7 +545,6 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nnrm)) < 0.906 || nlen == 0.0f) continue;
             const GIRes N = fr.gi[ni];                                       // accepted: now the reservoir
             Z += N.M;
-            if (!haveVp) { const GIRes Rs = fr.gi[src]; rvp = mk3(Rs.s.vp[0], Rs.s.vp[1], Rs.s.vp[2]); haveVp = true; }      // the current sample's visible point
             f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
             const f3 sn = oct_decode(sne);
             const f3 nvp = mk3(N.s.vp[0], N.s.vp[1], N.s.vp[2]), nsp = mk3(N.s.sp[0], N.s.sp[1], N.s.sp[2]);
@@ -562,6 +562,8 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             S[0] = make_float4(__int_as_float((int)src), spdf, Wr, wSum);
             S[1] = make_float4(__int_as_float((int)M), __int_as_float((int)seed), __int_as_float((int)n), __int_as_float((int)Z));
             S[2] = make_float4(__int_as_float((int)ni), pdf, N.wSum, __int_as_float((int)N.M));
+            if (rvpChanged) S[3] = f3f(rvp, 0.0f);
+            S[4] = f3f(nvp, 0.0f);
             return true;
         }
     }
