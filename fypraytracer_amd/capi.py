@@ -128,6 +128,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_group_synchronize", "fyprt_comm_unique_id", "fyprt_comm_init_rank", "fyprt_comm_set_rows", "fyprt_comm_set_halo_mode", "fyprt_comm_render",
     "fyprt_comm_gather", "fyprt_comm_destroy", "fyprt_render_part", "fyprt_balance_rows", "fyprt_last_frame_ms", "fyprt_halo_plan",
     "fyprt_set_object_vertices", "fyprt_update_transforms", "fyprt_compare_image",
+    "fyprt_set_row_stripes", "fyprt_group_set_interleave", "fyprt_comm_set_interleave",
 ]
 
 
@@ -185,6 +186,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_group_destroy.restype = None
     lib.fyprt_group_set_rows.argtypes = [vp, C.POINTER(u32)]
     lib.fyprt_group_set_halo_mode.argtypes = [vp, C.c_int]
+    lib.fyprt_group_set_interleave.argtypes = [vp, u32]
+    lib.fyprt_comm_set_interleave.argtypes = [vp, u32]
+    lib.fyprt_set_row_stripes.argtypes = [vp, u32, u32, u32]
     lib.fyprt_group_render.argtypes = [vp, C.POINTER(Settings)]
     lib.fyprt_group_gather.argtypes = [vp, C.c_int]
     lib.fyprt_group_synchronize.argtypes = [vp]
@@ -296,6 +300,10 @@ class Context:
 
     def set_rows(self, row_begin, row_end, halo_rows=0):
         self._check(self.lib.fyprt_set_rows(self.h, row_begin, row_end, halo_rows))
+
+    def set_row_stripes(self, stripe_rows, parts=1, part=0):
+        """Interleaved split of the per-pixel techniques: this context renders stripes part, part + parts, ... (0 rows = off)."""
+        self._check(self.lib.fyprt_set_row_stripes(self.h, stripe_rows, parts, part))
 
     def upload_scene(self, scene, light_trees=None):
         d, keep = make_scene_desc(scene, light_trees)
@@ -434,6 +442,9 @@ class Group:
 
     def set_halo_mode(self, mode):
         self._check(self.lib.fyprt_group_set_halo_mode(self.h, mode))
+
+    def set_interleave(self, stripe_rows):
+        self._check(self.lib.fyprt_group_set_interleave(self.h, stripe_rows))
 
     def set_rows(self, row_bounds):
         self._check(self.lib.fyprt_group_set_rows(self.h, _u32_array(row_bounds)))

@@ -57,6 +57,8 @@ struct fyprt_context {
     static constexpr int kRing = 128;          // frames whose per-launch hipEvents are kept (fyprt_frame_timings)
     hipEvent_t ring[kRing][5] = {}; int ringLaunches[kRing] = {}; unsigned long long frameSerial = 0; hipEvent_t* ev = nullptr;
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
+    uint32_t stripeRows = 0, stripeParts = 1, stripePart = 0;       // fyprt_set_row_stripes (per-pixel techniques only)
+    uint32_t commStripeRows = 0; bool commLastStriped = false;
     bool haloExchange = false;   // halo rows of ReSTIR Part 1 come from the bands that own them (fyprt_multi.h) instead of being recomputed here
     bool part1Pending = false;   // fyprt_render_part(1) was called, part 2 must follow
     uint32_t histDI[2] = {0, 0}, histGI[2] = {0, 0};   // rows [begin, end) whose ReSTIR DI / GI history this context holds (the band of the last such frame)
@@ -221,17 +223,39 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemsetAsync(c->gi.p, 0, c->gi.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->giPrev.p, 0, c->giPrev.bytes(), c->stream));
     HIPCHK(c, sync_all(c));
     c->part1Pending = false;
+    c->stripeRows = 0; c->stripeParts = 1; c->stripePart = 0;
     c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->externalImage = nullptr;
     c->histDI[0] = c->histGI[0] = 0; c->histDI[1] = c->histGI[1] = h;        // zero-filled history: "valid" everywhere, M = 0
     if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
     return FYPRT_OK;
 }
 
+// rows of the frame a striped context owns: the stripes k * parts + part, the last one cut at the frame's end
+static uint32_t stripe_row_count(uint32_t H, uint32_t stripe, uint32_t parts, uint32_t part) {
+    uint32_t n = 0;
+    for (uint64_t r0 = (uint64_t)part * stripe; r0 < H; r0 += (uint64_t)parts * stripe) n += (uint32_t)std::min<uint64_t>(stripe, H - r0);
+    return n;
+}
+
 int fyprt_set_rows(fyprt_context* c, uint32_t b, uint32_t e, uint32_t halo) {
     if (!c) return FYPRT_EINVAL;
     if (c->H == 0) return c->fail(FYPRT_ESTATE, "fyprt_set_rows before fyprt_resize");
     if (b >= e || e > c->H) return c->fail(FYPRT_EINVAL, "fyprt_set_rows: need row_begin < row_end <= height");
-    c->rowBegin = b; c->rowEnd = e; c->halo = halo; c->rowsSet = true;
+    c->rowBegin = b; c->rowEnd = e; c->halo = halo; c->rowsSet = true; c->stripeRows = 0;
+    return FYPRT_OK;
+}
+// The interleaved split of SURVEY.md §8(e) for the techniques whose pixels are independent (0-6): the frame is cut into stripes of
+// `stripe_rows` rows and this context renders every `parts`-th of them, starting with stripe `part` — the stripes of one context
+// sample the whole image, so the parts cost the same without any balancing.  stripe_rows 0 returns to the band of fyprt_set_rows
+// (whole frame if none was set).  ReSTIR frames refuse a striped context: spatial reuse reads the rows around a pixel.
+int fyprt_set_row_stripes(fyprt_context* c, uint32_t stripe_rows, uint32_t parts, uint32_t part) {
+    if (!c) return FYPRT_EINVAL;
+    if (c->H == 0) return c->fail(FYPRT_ESTATE, "fyprt_set_row_stripes before fyprt_resize");
+    if (stripe_rows == 0) { c->stripeRows = 0; c->stripeParts = 1; c->stripePart = 0; return FYPRT_OK; }
+    if (parts == 0 || part >= parts) return c->fail(FYPRT_EINVAL, "fyprt_set_row_stripes: need part < parts");
+    if (stripe_row_count(c->H, stripe_rows, parts, part) == 0) return c->fail(FYPRT_EINVAL, "fyprt_set_row_stripes: this part owns no row (fewer stripes than parts)");
+    c->stripeRows = stripe_rows; c->stripeParts = parts; c->stripePart = part;
+    c->rowBegin = 0; c->rowEnd = c->H; c->halo = 0; c->rowsSet = false;
     return FYPRT_OK;
 }
 
@@ -670,6 +694,9 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
     fr.di = c->di.p; fr.diPrev = c->diPrev.p; fr.gi = c->gi.p; fr.giPrev = c->giPrev.p; fr.giHot = c->giHot.p;
     fr.drec = c->drec.p; fr.dprevRead = c->dprevFlip ? c->dprevB.p : c->dprevA.p; fr.dprevWrite = c->dprevFlip ? c->dprevA.p : c->dprevB.p;
     fr.W = c->W; fr.H = c->H; fr.frameIndex = c->frameIndex; fr.rowBegin = c->rowBegin; fr.rowEnd = c->rowEnd;
+    fr.stripeRows = 0; fr.stripeParts = 1; fr.stripePart = 0;
+    const bool striped = c->stripeRows != 0 && c->stripeRows < c->H && c->stripeParts > 1;
+    if (striped && (tech == FYPRT_RESTIR_DI || tech == FYPRT_RESTIR_GI)) return c->fail(FYPRT_ESTATE, "ReSTIR frames need contiguous rows: clear fyprt_set_row_stripes first");
     fr.histBegin = (tech == FYPRT_RESTIR_GI) ? c->histGI[0] : c->histDI[0]; fr.histEnd = (tech == FYPRT_RESTIR_GI) ? c->histGI[1] : c->histDI[1];
     c->dsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
     // node-loop quorum of the fused per-pixel kernels (key 7): 0 = auto — 16 for the light-tree kernels (their shadow rays: NEE 5.2 -> 4.95 ms),
@@ -772,13 +799,19 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
             const uint32_t nSamples = (tech == FYPRT_BRUTE_FORCE) ? 1u : st.sampleCount;
             const uint32_t steps = (tech == FYPRT_LIGHT_SOURCE_SAMPLING) ? nSamples : nSamples * st.maxBounces;
             const uint32_t raysPer = (tech == FYPRT_NEE && st.maxBounces != 1u) ? 2u : 1u;
-            const size_t entries = (size_t)(c->rowEnd - c->rowBegin) * c->W, L = (size_t)steps + 2;
+            dim3 pgrid = grid;
+            if (striped) {                                           // k_primary maps the local rows [0, n) onto this context's stripes
+                fr.stripeRows = c->stripeRows; fr.stripeParts = c->stripeParts; fr.stripePart = c->stripePart;
+                fr.rowBegin = 0; fr.rowEnd = stripe_row_count(c->H, c->stripeRows, c->stripeParts, c->stripePart);
+                pgrid = gridFor(fr.rowBegin, fr.rowEnd);
+            }
+            const size_t entries = (size_t)(fr.rowEnd - fr.rowBegin) * c->W, L = (size_t)steps + 2;
             const uint32_t stride = (tech == FYPRT_NEE) ? 6u : 2u;
             { const int rc = ensure_paths(c, entries, raysPer, stride, 3 * L); if (rc != FYPRT_OK) return rc; }
             HIPCHK(c, hipMemsetAsync(c->wfCounters.p, 0, 3 * L * sizeof(uint32_t), c->stream));
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // coherent primary rays
-            if (c->countRays) hipLaunchKernelGGL(k_primary<true>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
-            else hipLaunchKernelGGL(k_primary<false>, grid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
+            if (c->countRays) hipLaunchKernelGGL(k_primary<true>, pgrid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
+            else hipLaunchKernelGGL(k_primary<false>, pgrid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
             StageRun r{tech, steps, raysPer, stride, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, (tech == FYPRT_NEE) ? c->wfPixels2.p : nullptr, nullptr, 0, (tech == FYPRT_NEE) ? c->wfCounters.p + 2 * L : nullptr, entries};
             { const int rc = run_stage(r); if (rc != FYPRT_OK) return rc; }
             launches = 1;

@@ -61,6 +61,11 @@ std::vector<XBuf> exchange_buffers(fyprt_context* c, int tech, int kind) {
     }
     return v;
 }
+bool is_restir(const fyprt_settings* s) { return s->technique == FYPRT_RESTIR_DI || s->technique == FYPRT_RESTIR_GI; }
+// stripes of part `part` of an interleaved split, as (first row, end row) — the same walk as stripe_row_count
+template <class F> void for_each_stripe(uint32_t H, uint32_t stripe, uint32_t parts, uint32_t part, F&& f) {
+    for (uint64_t r0 = (uint64_t)part * stripe; r0 < H; r0 += (uint64_t)parts * stripe) f((uint32_t)r0, (uint32_t)std::min<uint64_t>(r0 + stripe, H));
+}
 bool wants_exchange(const fyprt_settings* s) { return (s->technique == FYPRT_RESTIR_DI || s->technique == FYPRT_RESTIR_GI) && s->use_spatial_reuse; }
 void extend_history_rows(fyprt_context* c, int tech, uint32_t halo) {
     uint32_t* h = tech == FYPRT_RESTIR_DI ? c->histDI : c->histGI;
@@ -95,6 +100,7 @@ constexpr int kNcclChar = 0;      // ncclInt8 / ncclChar: transfers are counted 
 
 struct fyprt_group {
     std::vector<fyprt_context*> ctx; std::vector<uint32_t> bounds; int haloMode = 0;
+    uint32_t stripeRows = 0; bool lastStriped = false;      // interleaved split for the per-pixel techniques; whether the last frame used it
     std::vector<hipEvent_t> evP1, evPulled, evFrame; hipEvent_t evGather = nullptr; bool gatherPending = false; std::string err;
 };
 
@@ -168,6 +174,16 @@ int fyprt_group_set_rows(fyprt_group* g, const uint32_t* row_bounds) {
     return FYPRT_OK;
 }
 int fyprt_group_set_halo_mode(fyprt_group* g, int mode) { if (!g || mode < 0 || mode > 1) return FYPRT_EINVAL; g->haloMode = mode; return FYPRT_OK; }
+// Interleaved bands for the techniques without spatial reuse: context i renders the stripes of `stripe_rows` rows with
+// index i modulo n — see fyprt_set_row_stripes.  ReSTIR frames keep the contiguous bands.  0 = contiguous bands for everything.
+// A change takes effect with the next frame and, like a technique change in the reference (Renderer::ResetFrameIndex), wants the
+// accumulation restarted: the rows a context has accumulated are the rows it rendered.
+int fyprt_group_set_interleave(fyprt_group* g, uint32_t stripe_rows) {
+    if (!g) return FYPRT_EINVAL;
+    if (stripe_rows != 0 && (uint64_t)stripe_rows * g->ctx.size() > g->ctx[0]->H) return g->ctx[0]->fail(FYPRT_EINVAL, "fyprt_group_set_interleave: fewer stripes than contexts");
+    g->stripeRows = stripe_rows;
+    return FYPRT_OK;
+}
 
 // One frame on every band (asynchronous: returns when everything is enqueued; fyprt_group_synchronize / fyprt_synchronize wait).
 int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
@@ -177,9 +193,13 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
     const bool restir = wants_exchange(s);
     const uint32_t halo = (restir && n > 1) ? ((uint32_t)s->spatial_neighbor_radius & 0xFFu) : 0u;      // the kernels' uint8 cast (R.cu:1897)
     const bool exchange = g->haloMode == 1 && halo > 0;
+    const bool striped = g->stripeRows != 0 && n > 1 && !is_restir(s);
+    g->lastStriped = striped;
     for (int i = 0; i < n; ++i) {
         fyprt_context* c = g->ctx[i];
         c->rowBegin = g->bounds[i]; c->rowEnd = g->bounds[i + 1]; c->halo = halo; c->rowsSet = true; c->haloExchange = exchange;
+        if (striped) { const int rc = fyprt_set_row_stripes(c, g->stripeRows, (uint32_t)n, (uint32_t)i); if (rc != FYPRT_OK) return rc; }
+        else c->stripeRows = 0;
         // the previous frame's gather still reads this band's image rows on the root's stream: the new frame's epilogues wait for it
         if (g->gatherPending) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamWaitEvent(c->stream, g->evGather, 0)); }
     }
@@ -247,8 +267,14 @@ int fyprt_group_gather(fyprt_group* g, int root) {
         fyprt_context* c = g->ctx[i];
         HIPCHK(r, hipStreamWaitEvent(r->stream, g->evFrame[i], 0));
         const uint32_t* src = c->externalImage ? c->externalImage : c->image.p;
-        const size_t off = (size_t)g->bounds[i] * r->W, cnt = (size_t)(g->bounds[i + 1] - g->bounds[i]) * r->W;
-        HIPCHK(r, hipMemcpyPeerAsync(dst + off, r->device, src + off, c->device, cnt * 4, r->stream));
+        hipError_t e = hipSuccess;
+        auto rows = [&](uint32_t r0, uint32_t r1) {
+            const size_t off = (size_t)r0 * r->W, cnt = (size_t)(r1 - r0) * r->W;
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst + off, r->device, src + off, c->device, cnt * 4, r->stream);
+        };
+        if (g->lastStriped) for_each_stripe(r->H, g->stripeRows, (uint32_t)g->ctx.size(), (uint32_t)i, rows);
+        else rows(g->bounds[i], g->bounds[i + 1]);
+        HIPCHK(r, e);
     }
     HIPCHK(r, hipEventRecord(g->evGather, r->stream));
     g->gatherPending = true;
@@ -347,6 +373,13 @@ int fyprt_comm_set_rows(fyprt_context* c, const uint32_t* row_bounds) {
     return FYPRT_OK;
 }
 int fyprt_comm_set_halo_mode(fyprt_context* c, int mode) { if (!c || mode < 0 || mode > 1) return FYPRT_EINVAL; c->commHaloMode = mode; return FYPRT_OK; }
+// fyprt_group_set_interleave for one process per GPU (every rank calls it with the same value)
+int fyprt_comm_set_interleave(fyprt_context* c, uint32_t stripe_rows) {
+    if (!c || !c->comm) return FYPRT_EINVAL;
+    if (stripe_rows != 0 && (uint64_t)stripe_rows * c->world > c->H) return c->fail(FYPRT_EINVAL, "fyprt_comm_set_interleave: fewer stripes than ranks");
+    c->commStripeRows = stripe_rows;
+    return FYPRT_OK;
+}
 void fyprt_comm_destroy(fyprt_context* c) { if (c && c->comm && g_rccl.lib) { (void)hipSetDevice(c->device); (void)sync_all(c); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->haloExchange = false; } }
 
 static int comm_exchange(fyprt_context* c, int tech, const std::vector<HaloXfer>& plan, int kind) {
@@ -369,6 +402,9 @@ int fyprt_comm_render(fyprt_context* c, const fyprt_settings* s) {
     const uint32_t halo = (restir && c->world > 1) ? ((uint32_t)s->spatial_neighbor_radius & 0xFFu) : 0u;
     const bool exchange = c->commHaloMode == 1 && halo > 0;
     c->rowBegin = c->bounds[c->rank]; c->rowEnd = c->bounds[c->rank + 1]; c->halo = halo; c->rowsSet = true; c->haloExchange = exchange;
+    c->commLastStriped = c->commStripeRows != 0 && c->world > 1 && !is_restir(s);
+    if (c->commLastStriped) { const int rc = fyprt_set_row_stripes(c, c->commStripeRows, (uint32_t)c->world, (uint32_t)c->rank); if (rc != FYPRT_OK) return rc; }
+    else c->stripeRows = 0;
     if (!exchange) return enqueue_frame(c, s, true);
     HIPCHK(c, hipSetDevice(c->device));
     if (s->use_temporal_reuse) { const int rc = comm_exchange(c, s->technique, halo_plan(c->bounds, halo, c->H, false), 1); if (rc != FYPRT_OK) return rc; }
@@ -387,16 +423,25 @@ int fyprt_comm_gather(fyprt_context* c, int root) {
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t* img = c->externalImage ? c->externalImage : c->image.p;
     NCCLCHK(c, g_rccl.GroupStart());
+    int bad = 0;
     for (int r = 0; r < c->world; ++r) {
-        uint32_t* band = img + (size_t)c->bounds[r] * c->W;
-        const size_t bytes = (size_t)(c->bounds[r + 1] - c->bounds[r]) * c->W * 4;
-        if (root < 0) NCCLCHK(c, g_rccl.Broadcast(band, band, bytes, kNcclChar, r, c->comm, c->stream));
-        else if (r != root) {
-            if (c->rank == r) NCCLCHK(c, g_rccl.Send(band, bytes, kNcclChar, root, c->comm, c->stream));
-            else if (c->rank == root) NCCLCHK(c, g_rccl.Recv(band, bytes, kNcclChar, r, c->comm, c->stream));
-        }
+        auto rows = [&](uint32_t r0, uint32_t r1) {
+            uint32_t* band = img + (size_t)r0 * c->W;
+            const size_t bytes = (size_t)(r1 - r0) * c->W * 4;
+            int e = 0;
+            if (root < 0) e = g_rccl.Broadcast(band, band, bytes, kNcclChar, r, c->comm, c->stream);
+            else if (r != root) {
+                if (c->rank == r) e = g_rccl.Send(band, bytes, kNcclChar, root, c->comm, c->stream);
+                else if (c->rank == root) e = g_rccl.Recv(band, bytes, kNcclChar, r, c->comm, c->stream);
+            }
+            if (e != 0 && bad == 0) bad = e;
+        };
+        if (c->commLastStriped) for_each_stripe(c->H, c->commStripeRows, (uint32_t)c->world, (uint32_t)r, rows);      // one transfer per stripe, all in one group
+        else rows(c->bounds[r], c->bounds[r + 1]);
     }
-    NCCLCHK(c, g_rccl.GroupEnd());
+    const int endRc = g_rccl.GroupEnd();
+    if (bad != 0) return c->fail(FYPRT_EHIP, std::string("fyprt_comm_gather: ") + g_rccl.GetErrorString(bad));
+    NCCLCHK(c, endRc);
     return FYPRT_OK;
 }
 

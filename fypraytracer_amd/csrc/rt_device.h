@@ -58,6 +58,8 @@ struct DevFrame {
     DIRec* drec; const DIRec* dprevRead; DIRec* dprevWrite;   // DI: this frame's records; previous frame's (read) / next frame's history (write)
     uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder;
     uint32_t histBegin, histEnd;   // rows whose ReSTIR history (previous frame) this context holds: the band it rendered last frame
+    uint32_t stripeRows, stripeParts, stripePart;   // interleaved multi-GPU split of the per-pixel techniques (fyprt_set_row_stripes): this context
+                       // renders the stripes of `stripeRows` rows whose index is `stripePart` modulo `stripeParts`; stripeRows 0 = the contiguous band
     uint32_t p1Mode;   // ReSTIR DI Part 1: 0 = writes the image sentinel and the epilogue of finished pixels itself (reference protocol, R.cu:2746-2750);
                        // 1 = touches neither image nor accumulation: the wavefront Part 2 derives "finished" from the payload and runs every epilogue
 };

@@ -79,7 +79,12 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_primary(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t* pixelList, uint32_t* listCount) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
     uint32_t x, y;
-    const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
+    bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
+    if (fr.stripeRows != 0u) {                                   // [rowBegin, rowEnd) counts this context's rows, stripe after stripe: local row -> image row
+        const uint32_t k = y / fr.stripeRows;
+        y = (k * fr.stripeParts + fr.stripePart) * fr.stripeRows + (y - k * fr.stripeRows);
+        inside = inside && y < fr.H;
+    }
     const uint32_t i = x + y * fr.W;
     bool live = false;
     if (inside) {

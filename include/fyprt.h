@@ -180,6 +180,12 @@ int fyprt_resize(fyprt_context* ctx, uint32_t width, uint32_t height);
  * [row_begin,row_end) of the full width x height frame.  ReSTIR Part 1 is additionally run
  * on `halo_rows` rows either side (halo recompute).  Default: all rows. */
 int fyprt_set_rows(fyprt_context* ctx, uint32_t row_begin, uint32_t row_end, uint32_t halo_rows);
+/* The interleaved split of SURVEY.md §8(e) for the techniques whose pixels are independent (every technique but the two ReSTIRs:
+ * PerPixel_* of Renderer.cu:565-1626 read nothing of another pixel): the frame is cut into stripes of `stripe_rows` rows and this
+ * context renders the stripes part, part + parts, part + 2 parts, ... — every part samples the whole image, so the parts cost the
+ * same without balancing.  stripe_rows 0 returns to the rows of fyprt_set_rows.  A ReSTIR frame on a striped context fails with
+ * FYPRT_ESTATE (spatial reuse reads the rows around a pixel).  Pixel values do not depend on the split. */
+int fyprt_set_row_stripes(fyprt_context* ctx, uint32_t stripe_rows, uint32_t parts, uint32_t part);
 
 /* SceneToGPU / FreeSceneGPU (Scene_GPU.cpp:6-163) + Renderer::SetSceneToBeUpdatedFlag(true)
  * (Renderer.h:56): builds the acceleration structure and uploads everything. */
@@ -317,6 +323,9 @@ int fyprt_group_create(fyprt_context** contexts, int n, const uint32_t* row_boun
 void fyprt_group_destroy(fyprt_group* group);                       /* the contexts stay alive */
 int fyprt_group_set_rows(fyprt_group* group, const uint32_t* row_bounds);
 int fyprt_group_set_halo_mode(fyprt_group* group, int mode);
+/* stripe_rows > 0: frames of the per-pixel techniques are split into interleaved stripes (fyprt_set_row_stripes, context i = part i),
+ * ReSTIR frames keep the row bands; the gather moves stripes instead of bands.  Restart the accumulation when changing it. */
+int fyprt_group_set_interleave(fyprt_group* group, uint32_t stripe_rows);
 int fyprt_group_render(fyprt_group* group, const fyprt_settings* settings);   /* one frame on every band; asynchronous */
 int fyprt_group_gather(fyprt_group* group, int root);               /* all bands' RGBA8 rows into context `root`'s image; asynchronous */
 int fyprt_group_synchronize(fyprt_group* group);
@@ -326,6 +335,7 @@ int fyprt_comm_unique_id(void* id128);
 int fyprt_comm_init_rank(fyprt_context* ctx, int world_size, int rank, const void* id128, const uint32_t* row_bounds);
 int fyprt_comm_set_rows(fyprt_context* ctx, const uint32_t* row_bounds);
 int fyprt_comm_set_halo_mode(fyprt_context* ctx, int mode);
+int fyprt_comm_set_interleave(fyprt_context* ctx, uint32_t stripe_rows);       /* as fyprt_group_set_interleave; same value on every rank */
 int fyprt_comm_render(fyprt_context* ctx, const fyprt_settings* settings);    /* this rank's band; collective (every rank calls it); asynchronous */
 int fyprt_comm_gather(fyprt_context* ctx, int root /* < 0: every rank gets the frame */);   /* grouped ncclBroadcast per band, in place */
 void fyprt_comm_destroy(fyprt_context* ctx);

@@ -173,3 +173,90 @@ def test_asynchronous_frames_with_a_gather_per_frame():
     grp.close()
     for c in ctxs:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------- interleaved stripes
+def _owned_rows(H, stripe, parts, part):
+    return np.array([y for y in range(H) if (y // stripe) % parts == part], np.int64)
+
+
+@pytest.mark.parametrize("tech", [capi.BRUTE_FORCE, capi.COSINE_WEIGHTED_SAMPLING, capi.LIGHT_SOURCE_SAMPLING, capi.NEE])
+@pytest.mark.parametrize("stripe,parts", [(16, 3), (8, 4), (5, 2)])
+def test_striped_context_renders_exactly_its_stripes(tech, stripe, parts):
+    """fyprt_set_row_stripes: part k of n renders the stripes k, k + n, ... — bit for bit the single-context pixels there (the
+    techniques' pixels are independent), and touches nothing else.  H = 100 leaves a cut last stripe; stripe 5 is not a multiple of
+    the 8-row wave tile (placement is free, results are not)."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 96, 100
+    cam = mk_cam(W, H)
+    ref = _single(sc, cam, W, H, tech, 2)
+    ctx = _contexts(1, sc, cam, W, H)[0]
+    st = settings_for(tech)
+    seen = np.zeros(H, bool)
+    for part in range(parts):
+        ctx.resize(W, H)                                      # zero image / accumulation
+        ctx.set_row_stripes(stripe, parts, part)
+        for f in range(2):
+            st.rand_seed = f + 1
+            ctx.render(st)
+        img, acc = ctx.readback()
+        rows = _owned_rows(H, stripe, parts, part)
+        other = np.setdiff1d(np.arange(H), rows)
+        assert bits_equal(acc[rows], ref[1][1][rows]).all() and np.array_equal(img[rows], ref[1][0][rows])
+        assert not acc[other].any() and not img[other].any()
+        seen[rows] = True
+    assert seen.all()
+    ctx.set_row_stripes(0)                                    # back to the whole frame
+    ctx.resize(W, H)
+    st.rand_seed = 1
+    ctx.render(st)
+    assert np.array_equal(ctx.readback(want_accum=False)[0], ref[0][0])
+    ctx.close()
+
+
+def test_restir_refuses_stripes_and_bad_arguments():
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 64, 64
+    ctx = _contexts(1, sc, mk_cam(W, H), W, H)[0]
+    with pytest.raises(capi.FyprtError):
+        ctx.set_row_stripes(16, 2, 2)                         # part >= parts
+    with pytest.raises(capi.FyprtError):
+        ctx.set_row_stripes(16, 8, 7)                         # 4 stripes only: part 7 owns nothing
+    ctx.set_row_stripes(16, 2, 1)
+    for tech in (capi.RESTIR_DI, capi.RESTIR_GI):
+        with pytest.raises(capi.FyprtError, match="contiguous"):
+            ctx.render(settings_for(tech))
+    ctx.render(settings_for(capi.NEE))                        # still usable
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,stripe", [(2, 16), (3, 8), (5, 16)])
+def test_group_interleave_gathers_the_single_gpu_frame(n, stripe):
+    """fyprt_group_set_interleave: the per-pixel techniques run striped and the gather moves stripes; a ReSTIR frame of the same group
+    keeps the row bands (with the halo exchange) — both equal the single-context frames bit for bit."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 128, 168
+    cam = mk_cam(W, H)
+    bounds = [round(H * k / n) for k in range(n + 1)]
+    ctxs = _contexts(n, sc, cam, W, H)
+    grp = capi.Group(ctxs, bounds, halo_mode=1)
+    grp.set_interleave(stripe)
+    for tech in (capi.NEE, capi.RESTIR_DI, capi.GGX_SAMPLING):
+        ref = _single(sc, cam, W, H, tech, 3)
+        for c in ctxs:
+            c.resize(W, H)                                    # new technique: accumulation restarts (Renderer::ResetFrameIndex)
+        st = settings_for(tech)
+        for f in range(3):
+            st.rand_seed = f + 1
+            grp.render(st)
+            grp.gather(0)
+            grp.synchronize()
+            ctxs[0].set_row_stripes(0)
+            ctxs[0].set_rows(0, H, 0)
+            full, _ = ctxs[0].readback(want_accum=False)
+            assert np.array_equal(full, ref[f][0]), f"technique {tech}, frame {f + 1}"
+    with pytest.raises(capi.FyprtError):
+        grp.set_interleave(H)                                 # fewer stripes than contexts
+    grp.close()
+    for c in ctxs:
+        c.close()

@@ -6,6 +6,7 @@ gather), so a split's frame time is its slowest band (+ the transfer estimate be
              are those of a preceding full-frame render, so Part 2 does realistic work); the exchange itself is priced at
              bytes / 50 GB/s per direction (one xGMI link: MI355X_MICROARCH.md) + 20 us, and reported separately;
   --balance K  K rounds of fyprt_balance_rows on the measured band times before the final measurement (cost-balanced bands).
+  --stripes S  (per-pixel techniques 0-6) interleaved stripes of S rows instead of bands: part r of n = fyprt_set_row_stripes(S, n, r).
 One JSON line per band and one summary line per split: {"n", "mode", "bounds", "slowest_band_ms", "speedup_vs_1"}."""
 import argparse
 import json
@@ -31,6 +32,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mode", default="recompute", choices=["recompute", "exchange"])
     ap.add_argument("--balance", type=int, default=0)
+    ap.add_argument("--stripes", type=int, default=0)
     a = ap.parse_args()
     W, H = a.width, a.height
     sc, cam = scenes.hall_scene(), scenes.hall_camera(W, H)
@@ -41,8 +43,9 @@ def main():
     st = capi.Settings(technique=a.technique, light_bounces=1 if a.technique == 7 else 2, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
     per_px_bytes = {7: (32, 32), 8: (96, 72)}.get(a.technique, (0, 0))     # Part-1 records, history (fyprt_multi.h)
 
-    def time_band(y0, y1, halo):
+    def time_band(y0, y1, halo, stripe_part=None):
         ctx.set_tuning(13, 0)
+        ctx.set_row_stripes(0)
         ctx.set_rows(0, H, 0)
         ctx.reset_frame_index()
         for f in range(2):                                   # sane records in every row (the halo rows of exchange mode are read, not written)
@@ -50,6 +53,8 @@ def main():
             ctx.render_async(st)
         ctx.set_tuning(13, 1 if a.mode == "exchange" else 0)
         ctx.set_rows(y0, y1, halo)
+        if stripe_part is not None:
+            ctx.set_row_stripes(a.stripes, *stripe_part)
         for f in range(8):
             st.rand_seed = f + 3
             ctx.render_async(st)
@@ -70,12 +75,12 @@ def main():
         for it in range(a.balance + 1 if n > 1 else 1):
             rows = []
             for r in range(n):
-                wall, parts = time_band(bounds[r], bounds[r + 1], halo)
+                wall, parts = time_band(bounds[r], bounds[r + 1], halo, (n, r) if a.stripes and n > 1 else None)
                 xfer = 0.0
                 if a.mode == "exchange" and n > 1:
                     halo_rows = min(halo, bounds[r]) + min(halo, H - bounds[r + 1])
                     xfer = (halo_rows * W * sum(per_px_bytes)) / (XGMI_GBS * 1e9) * 1e3 / 2 + 0.02    # both neighbours in parallel
-                rows.append({"n": n, "mode": a.mode, "balance_round": it, "rank": r, "rows": [bounds[r], bounds[r + 1]], "wall_ms_per_frame": round(wall, 4),
+                rows.append({"n": n, "mode": a.mode if not a.stripes else f"stripes{a.stripes}", "balance_round": it, "rank": r, "rows": [bounds[r], bounds[r + 1]], "wall_ms_per_frame": round(wall, 4),
                              "launch_ms": parts, "exchange_ms_estimate": round(xfer, 4)})
             final = it == (a.balance if n > 1 else 0)
             if final:
@@ -86,7 +91,7 @@ def main():
         slow = max(x["wall_ms_per_frame"] + x["exchange_ms_estimate"] for x in rows)
         if n == 1:
             base = slow
-        print(json.dumps({"n": n, "mode": a.mode, "balanced_rounds": a.balance if n > 1 else 0, "bounds": bounds, "slowest_band_ms": round(slow, 4),
+        print(json.dumps({"n": n, "mode": a.mode if not a.stripes else f"stripes{a.stripes}", "balanced_rounds": a.balance if n > 1 else 0, "bounds": bounds, "slowest_band_ms": round(slow, 4),
                           "band_ms": [round(x["wall_ms_per_frame"], 4) for x in rows], "speedup_vs_1": round(base / slow, 2) if base else None,
                           "note": "projection from one GPU: each band timed alone, no fabric, exchange priced at 50 GB/s + 20 us"}), flush=True)
     ctx.close()
