@@ -59,6 +59,7 @@ struct fyprt_context {
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
     uint32_t stripeRows = 0, stripeParts = 1, stripePart = 0;       // fyprt_set_row_stripes (per-pixel techniques only)
     uint32_t commStripeRows = 0; bool commLastStriped = false;
+    int lastBuildRounds = 0;                                          // PLOC rounds of the last device build (diagnostic)
     bool haloExchange = false;   // halo rows of ReSTIR Part 1 come from the bands that own them (fyprt_multi.h) instead of being recomputed here
     bool part1Pending = false;   // fyprt_render_part(1) was called, part 2 must follow
     uint32_t histDI[2] = {0, 0}, histGI[2] = {0, 0};   // rows [begin, end) whose ReSTIR DI / GI history this context holds (the band of the last such frame)
@@ -282,30 +283,66 @@ static int run_refit(fyprt_context* c) {
 // level counts.  Leaves c->nodes (topology only), c->leafTris (triangle indices in sorted order) and the host copy of the
 // topology (for export and the level grouping); boxes come from run_refit.  kLbvhTooDeep: more than 31 wide levels.
 constexpr int kLbvhTooDeep = -1000;
-static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32_t nV, uint32_t nT) {
+static int env_int(const char* name, int fallback) { const char* v = std::getenv(name); return (v && *v) ? std::atoi(v) : fallback; }
+static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32_t nV, uint32_t nT, bool ploc) {
     float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (uint32_t i = 0; i < nV; ++i) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], verts[i].position[a]); hi[a] = std::max(hi[a], verts[i].position[a]); }
     float3 l3 = make_float3(lo[0], lo[1], lo[2]), ie = make_float3(hi[0] > lo[0] ? 1.0f / (hi[0] - lo[0]) : 0.0f, hi[1] > lo[1] ? 1.0f / (hi[1] - lo[1]) : 0.0f, hi[2] > lo[2] ? 1.0f / (hi[2] - lo[2]) : 0.0f);
     struct Temps {                      // scratch of the build, freed on every way out
         DevBuf<unsigned long long> keysA, keysB; DevBuf<uint32_t> valsA, valsB, parentOfNode, parentOfLeaf, arrived; DevBuf<float> box; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
-        ~Temps() { keysA.release(); keysB.release(); valsA.release(); valsB.release(); parentOfNode.release(); parentOfLeaf.release(); arrived.release(); box.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
+        DevBuf<uint32_t> clA, clB, nearest; DevBuf<uint8_t> keep;                                   // PLOC
+        ~Temps() { clA.release(); clB.release(); nearest.release(); keep.release(); keysA.release(); keysB.release(); valsA.release(); valsB.release(); parentOfNode.release(); parentOfLeaf.release(); arrived.release(); box.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
     } t;
     auto &keysA = t.keysA, &keysB = t.keysB; auto &valsA = t.valsA, &valsB = t.valsB; auto& radix = t.radix;
-    HIPCHK(c, t.parentOfNode.alloc(nT)); HIPCHK(c, t.parentOfLeaf.alloc(nT)); HIPCHK(c, t.arrived.alloc(nT)); HIPCHK(c, t.box.alloc((size_t)nT * 6));
-    HIPCHK(c, hipMemsetAsync(t.arrived.p, 0, (size_t)nT * 4, c->stream)); auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
+    if (!ploc) {
+        HIPCHK(c, t.parentOfNode.alloc(nT)); HIPCHK(c, t.parentOfLeaf.alloc(nT)); HIPCHK(c, t.arrived.alloc(nT)); HIPCHK(c, t.box.alloc((size_t)nT * 6));
+        HIPCHK(c, hipMemsetAsync(t.arrived.p, 0, (size_t)nT * 4, c->stream));
+    } else {
+        HIPCHK(c, t.box.alloc((size_t)nT * 12)); HIPCHK(c, t.clA.alloc(nT)); HIPCHK(c, t.clB.alloc(nT)); HIPCHK(c, t.nearest.alloc(nT)); HIPCHK(c, t.keep.alloc(nT));
+    } auto &qA = t.qA, &qB = t.qB; auto& counters = t.counters; auto& wide = t.wide; auto& temp = t.temp;
     HIPCHK(c, keysA.alloc(nT)); HIPCHK(c, keysB.alloc(nT)); HIPCHK(c, valsA.alloc(nT)); HIPCHK(c, valsB.alloc(nT)); HIPCHK(c, radix.alloc(nT)); HIPCHK(c, qA.alloc(nT)); HIPCHK(c, qB.alloc(nT));
-    HIPCHK(c, counters.alloc(2)); HIPCHK(c, wide.alloc((size_t)nT * 4));
+    HIPCHK(c, counters.alloc(4)); HIPCHK(c, wide.alloc((size_t)nT * 4));
     hipLaunchKernelGGL(k_lbvh_keys, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, c->triPos.p, nT, l3, ie, keysA.p, valsA.p);
     size_t tempBytes = 0;
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysA.p, keysB.p, valsA.p, valsB.p, (int)nT, 0, 63, c->stream));
     HIPCHK(c, temp.alloc(tempBytes));
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp.p, tempBytes, keysA.p, keysB.p, valsA.p, valsB.p, (int)nT, 0, 63, c->stream));
-    hipLaunchKernelGGL(k_lbvh_radix, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, (int)nT, radix.p, t.parentOfNode.p, t.parentOfLeaf.p);
-    hipLaunchKernelGGL(k_lbvh_boxes, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, radix.p, t.parentOfNode.p, t.parentOfLeaf.p, valsB.p, c->triPos.p, nT, t.arrived.p, t.box.p);
+    uint32_t rootNode = 0;
+    if (!ploc) {
+        hipLaunchKernelGGL(k_lbvh_radix, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, keysB.p, (int)nT, radix.p, t.parentOfNode.p, t.parentOfLeaf.p);
+        hipLaunchKernelGGL(k_lbvh_boxes, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, radix.p, t.parentOfNode.p, t.parentOfLeaf.p, valsB.p, c->triPos.p, nT, t.arrived.p, t.box.p);
+    } else {
+        // PLOC rounds over the sorted order (rt_lbvh.h).  Every round has at least one mutual pair (the pair of globally smallest
+        // union), real scenes lose 20-35 % of their clusters per round (54 rounds for 1 M triangles).  A round over a LONG list
+        // that loses less than 1/16 is followed by a forced one (neighbours i, i ^ 1 merge), which halves the list, so degenerate
+        // input cannot take O(n) rounds of O(n) work; short lists (the top of the tree, where quality counts most) are never forced.
+        const int radius = std::min(kPlocMaxRadius, std::max(1, env_int("FYPRT_PLOC_RADIUS", 16)));
+        hipLaunchKernelGGL(k_ploc_leaves, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, valsB.p, c->triPos.p, nT, t.box.p, t.clA.p);
+        HIPCHK(c, hipMemsetAsync(counters.p + 2, 0, 8, c->stream));                     // [2] binary nodes allocated, [3] clusters kept by the compaction
+        size_t selBytes = 0;
+        HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, selBytes, t.clB.p, t.keep.p, t.clA.p, counters.p + 3, (int)nT, c->stream));
+        DevBuf<uint8_t> selTemp; HIPCHK(c, selTemp.alloc(selBytes));
+        uint32_t n = nT; uint32_t* cur = t.clA.p; uint32_t* merged = t.clB.p; int force = 0, rounds = 0;
+        while (n > 1) {
+            const dim3 g((n + kPlocBlock - 1) / kPlocBlock);
+            hipLaunchKernelGGL(k_ploc_nearest, g, dim3(kPlocBlock), 0, c->stream, (const uint32_t*)cur, n, (const float*)t.box.p, nT, radius, force, t.nearest.p);
+            hipLaunchKernelGGL(k_ploc_merge, g, dim3(kPlocBlock), 0, c->stream, (const uint32_t*)cur, (const uint32_t*)t.nearest.p, n, nT, radix.p, t.box.p, counters.p + 2, merged, t.keep.p);
+            hipError_t e = hipcub::DeviceSelect::Flagged(selTemp.p, selBytes, merged, t.keep.p, cur, counters.p + 3, (int)n, c->stream);     // back into `cur`, order kept
+            uint32_t kept = 0;
+            if (e == hipSuccess) e = hipMemcpyAsync(&kept, counters.p + 3, 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess || kept == 0 || kept >= n) { selTemp.release(); return e != hipSuccess ? c->hip(e, "PLOC round") : c->fail(FYPRT_EHIP, "PLOC round made no progress"); }
+            if (env_int("FYPRT_BVH_DEBUG", 0)) std::fprintf(stderr, "PLOC round %d: %u -> %u clusters%s\n", rounds, n, kept, force ? " (forced)" : "");
+            force = (!force && n > 4096u && kept > n - n / 16u) ? 1 : 0;
+            n = kept; ++rounds;
+        }
+        HIPCHK(c, hipMemcpy(&rootNode, cur, 4, hipMemcpyDeviceToHost));
+        selTemp.release();
+        c->lastBuildRounds = rounds;
+    }
     HIPCHK(c, c->leafTris.alloc((size_t)nT * 3));
-    hipLaunchKernelGGL(k_lbvh_leaf_order, dim3((nT + 255u) / 256u), dim3(256), 0, c->stream, valsB.p, nT, c->leafTris.p);
     // BFS collapse, one launch per level; the nodes of a level are contiguous: [levelFirst[l], levelFirst[l + 1])
-    const CollapseItem rootItem{0u, 0u};
+    const CollapseItem rootItem{rootNode, 0u, 0u};
     uint32_t h_counters[2] = {1u, 0u};
     HIPCHK(c, hipMemcpyAsync(qA.p, &rootItem, sizeof rootItem, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(counters.p, h_counters, 8, hipMemcpyHostToDevice, c->stream));
@@ -313,7 +350,7 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
     uint32_t nIn = 1, total = 1;
     CollapseItem *in = qA.p, *out = qB.p;
     while (nIn) {
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3((nIn + 127u) / 128u), dim3(128), 0, c->stream, radix.p, t.box.p, in, nIn, out, counters.p, wide.p);
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3((nIn + 127u) / 128u), dim3(128), 0, c->stream, (const RadixNode*)radix.p, (const float*)t.box.p, (const uint32_t*)valsB.p, (const CollapseItem*)in, nIn, out, counters.p, wide.p, c->leafTris.p);
         HIPCHK(c, hipMemcpyAsync(h_counters, counters.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         levelFirst.push_back(total);
@@ -363,7 +400,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     struct HostOnlyGuard { bool prev; explicit HostOnlyGuard(bool on) : prev(g_hostOnlyAlloc) { g_hostOnlyAlloc = on; } ~HostOnlyGuard() { g_hostOnlyAlloc = prev; } } guard(c->hostOnly);
     // acceleration structure (ours): built on the host (binned SAH + collapse, bvh_build.cpp) or, with tuning key 12, on the
     // device (LBVH + collapse, rt_lbvh.h — further down, once the per-triangle records are on the device)
-    bool deviceBuild = !c->hostOnly && c->tuning[12] == 1 && s->triangle_count > 4;
+    bool deviceBuild = !c->hostOnly && c->tuning[12] != 0 && s->triangle_count > 4;
     auto hostBuild = [&]() -> int {
         rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
         if (c->hostBvh.levels > rth::kStackBudget || c->hostBvh.nodes.size() >= (size_t)(1u << 26))
@@ -398,7 +435,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     c->topoTris.resize((size_t)nT * 4);
     for (uint32_t i = 0; i < nT; ++i) std::memcpy(&c->topoTris[(size_t)i * 4], tri(i), 16);
     if (deviceBuild) {
-        const int rc = build_device_lbvh(c, s->vertices, s->vertex_count, nT);
+        const int rc = build_device_lbvh(c, s->vertices, s->vertex_count, nT, c->tuning[12] == 2);
         if (rc == kLbvhTooDeep) { deviceBuild = false; const int rc2 = hostBuild(); if (rc2 != FYPRT_OK) return rc2; }   // > 31 wide levels: the host builder bounds them
         else if (rc != FYPRT_OK) return rc;
     }
@@ -1099,7 +1136,7 @@ int fyprt_set_tuning(fyprt_context* c, int key, int value) {
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
     static const int lo[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[16] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 1, 1, 2, 2};
+    static const int hi[16] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

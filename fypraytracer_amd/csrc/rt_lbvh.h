@@ -12,6 +12,16 @@
 //   k_lbvh_levels    reverse BFS: levels(node) = 1 + max(levels(inner children)) into the node's meta byte
 // Boxes and their 8-bit quantisation are NOT computed here: the refit pass (rt_refit.h) does that for any topology.
 // Tree quality is that of an LBVH (no SAH): traversal is slower than with the host builder; the build takes milliseconds.
+//
+// Key 12 = 2 replaces the radix tree by PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) over the same sorted
+// order: the clusters — at first one per triangle, in Morton order — each look for the neighbour within `radius` positions whose
+// union with them has the smallest surface area; mutual choices merge into a new binary node that takes the lower position; the
+// list is compacted (order kept) and the round repeats until one cluster is left:
+//   k_ploc_leaves    leaf boxes + the initial cluster list
+//   k_ploc_nearest   one round's search, the window's boxes staged in LDS
+//   k_ploc_merge     mutual pairs -> binary node (children, size, box); survivors flagged
+//   (compaction)     hipcub::DeviceSelect::Flagged
+// The result is a binary tree in the radix tree's node format (sizes instead of key ranges), so the same collapse runs on it.
 #pragma once
 #include "rt_device.h"
 
@@ -98,21 +108,13 @@ __global__ void k_lbvh_boxes(const RadixNode* rn, const uint32_t* parentOfNode, 
     }
 }
 
-// leaf-triangle records in sorted order: only the triangle index here, k_refresh_leaf_tris fills in (v0, e1, e2)
-__global__ void k_lbvh_leaf_order(const uint32_t* vals, uint32_t n, float4* leafTris) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    leafTris[(size_t)j * 3 + 2] = make_float4(0.0f, __int_as_float((int)vals[j]), 0.0f, 0.0f);
-}
-
-struct CollapseItem { uint32_t radix, wide; };
+struct CollapseItem { uint32_t radix, wide, first; };      // binary node, its wide node, position of its first triangle in the leaf-triangle array
 #ifndef RT_LBVH_LEAF
 #define RT_LBVH_LEAF 4u
 #endif
 constexpr uint32_t kLbvhLeaf = RT_LBVH_LEAF;      // a radix subtree of at most this many triangles becomes one leaf
 
 RT_DEV uint32_t radix_span(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? 1u : rn[ref].last - rn[ref].first + 1u; }
-RT_DEV uint32_t radix_first(const RadixNode* rn, uint32_t ref) { return (ref & kRadixLeaf) ? (ref & ~kRadixLeaf) : rn[ref].first; }
 
 // counters[0]: wide nodes allocated so far; counters[1]: items written to `out`
 RT_DEV float lbvh_area(const float* box, uint32_t node) {
@@ -120,7 +122,12 @@ RT_DEV float lbvh_area(const float* box, uint32_t node) {
     const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
     return dx * dy + dy * dz + dz * dx;
 }
-__global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const CollapseItem* in, uint32_t nIn, CollapseItem* out, uint32_t* counters, float4* nodes) {
+// The triangles below a binary node occupy [first, first + span) of the leaf-triangle array, left subtree first — for the radix tree
+// that is the sorted order, for a PLOC tree (whose clusters are not runs of the sorted order) it is what makes a leaf's triangles
+// consecutive.  `vals` = triangle index per sorted position.
+__global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const uint32_t* vals, const CollapseItem* in, uint32_t nIn, CollapseItem* out, uint32_t* counters,
+                                float4* nodes, float4* leafTris) {
+    static_assert(kLbvhLeaf <= 4u, "a leaf reference holds count - 1 in two bits");
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nIn) return;
     const CollapseItem it = in[k];
@@ -134,21 +141,108 @@ __global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const Col
         for (int j = cnt; j > best + 1; --j) ch[j] = ch[j - 1];
         ch[best] = b.left; ch[best + 1] = b.right; ++cnt;
     }
+    while (cnt < 4) {                                             // slots left over: split the would-be leaf of largest area into its two halves
+        int best = -1; float bestArea = -1.0f;                    // (tighter boxes around fewer triangles at the price of nothing: the slots are tested anyway)
+        for (int i = 0; i < cnt; ++i) if (!(ch[i] & kRadixLeaf) && radix_span(rn, ch[i]) <= kLbvhLeaf) { const float ar = lbvh_area(box, ch[i]); if (ar > bestArea) { bestArea = ar; best = i; } }
+        if (best < 0) break;
+        const RadixNode b = rn[ch[best]];
+        for (int j = cnt; j > best + 1; --j) ch[j] = ch[j - 1];
+        ch[best] = b.left; ch[best + 1] = b.right; ++cnt;
+    }
     int32_t ref[4] = {(int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000};
+    uint32_t first = it.first;
     for (int i = 0; i < cnt; ++i) {
         const uint32_t sp = radix_span(rn, ch[i]);
-        if (sp <= kLbvhLeaf) ref[i] = ~(int32_t)((radix_first(rn, ch[i]) << 2) | (sp - 1u));
-        else {
+        if (sp <= kLbvhLeaf) {
+            ref[i] = ~(int32_t)((first << 2) | (sp - 1u));
+            uint32_t stack[4], top = 0, pos = first;                  // the leaf's triangles, left to right
+            stack[top++] = ch[i];
+            while (top) {
+                const uint32_t r = stack[--top];
+                if (r & kRadixLeaf) { leafTris[(size_t)pos * 3 + 2] = make_float4(0.0f, __int_as_float((int)vals[r & ~kRadixLeaf]), 0.0f, 0.0f); ++pos; }   // k_refresh_leaf_tris fills in (v0, e1, e2)
+                else { stack[top++] = rn[r].right; stack[top++] = rn[r].left; }
+            }
+        } else {
             const uint32_t w = atomicAdd(counters + 0, 1u);
             const uint32_t o = atomicAdd(counters + 1, 1u);
-            out[o] = CollapseItem{ch[i], w};
+            out[o] = CollapseItem{ch[i], w, first};
             ref[i] = (int32_t)w;
         }
+        first += sp;
     }
     float4* n = nodes + (size_t)it.wide * 4;
     n[0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float((int)((uint32_t)cnt << 24)));      // boxes + exponents: the refit pass
     n[1] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
     n[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); n[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+
+// ------------------------------------------------------------------------------------------------ PLOC (key 12 = 2)
+// Boxes: 6 floats per binary node; internal node k at slot k (what lbvh_area reads), leaf j (sorted position) at slot nLeaves + j.
+RT_DEV uint32_t ploc_slot(uint32_t ref, uint32_t nLeaves) { return (ref & kRadixLeaf) ? nLeaves + (ref & ~kRadixLeaf) : ref; }
+
+__global__ void k_ploc_leaves(const uint32_t* vals, const float4* triPos, uint32_t n, float* box, uint32_t* clusters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float b[6];
+    lbvh_leaf_box(triPos, vals[j], b);
+    for (int k = 0; k < 6; ++k) box[(size_t)(n + j) * 6 + k] = b[k];
+    clusters[j] = kRadixLeaf | j;
+}
+
+constexpr int kPlocBlock = 256, kPlocMaxRadius = 32;
+// nearest[i] = position of the cluster within `radius` whose union with cluster i has the smallest area; ties: the partner i ^ 1
+// first, then the lower position (with that, equal boxes pair up instead of forming a chain of one-sided choices).  force != 0:
+// everybody takes i ^ 1 — the host's way out of a round that merged almost nothing.
+__global__ __launch_bounds__(kPlocBlock) void k_ploc_nearest(const uint32_t* clusters, uint32_t n, const float* box, uint32_t nLeaves, int radius, int force, uint32_t* nearest) {
+    __shared__ float s_box[(kPlocBlock + 2 * kPlocMaxRadius) * 6];
+    const int base = (int)(blockIdx.x * kPlocBlock) - radius;
+    for (int t = (int)threadIdx.x; t < kPlocBlock + 2 * radius; t += kPlocBlock) {
+        const int g = base + t;
+        if (g >= 0 && g < (int)n) { const float* b = box + (size_t)ploc_slot(clusters[g], nLeaves) * 6; for (int k = 0; k < 6; ++k) s_box[t * 6 + k] = b[k]; }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kPlocBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t partner = ((i ^ 1u) < n) ? (i ^ 1u) : i - 1u;         // n >= 2
+    const float* me = s_box + ((int)threadIdx.x + radius) * 6;
+    auto cost = [&](int g) {
+        const float* o = s_box + (g - base) * 6;
+        const float dx = __builtin_fmaxf(me[3], o[3]) - __builtin_fminf(me[0], o[0]), dy = __builtin_fmaxf(me[4], o[4]) - __builtin_fminf(me[1], o[1]),
+                    dz = __builtin_fmaxf(me[5], o[5]) - __builtin_fminf(me[2], o[2]);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    uint32_t best = partner;
+    if (!force) {
+        float bestCost = cost((int)partner);
+        const int lo = (int)i - radius < 0 ? 0 : (int)i - radius, hi = (int)i + radius >= (int)n ? (int)n - 1 : (int)i + radius;
+        for (int g = lo; g <= hi; ++g) {
+            if (g == (int)i) continue;
+            const float cg = cost(g);
+            if (cg < bestCost) { bestCost = cg; best = (uint32_t)g; }      // NaN boxes never win: `best` stays a valid position
+        }
+    }
+    nearest[i] = best;
+}
+
+// mutual choices merge: the lower position keeps the new node, the upper one drops out of the list
+__global__ void k_ploc_merge(const uint32_t* clusters, const uint32_t* nearest, uint32_t n, uint32_t nLeaves, RadixNode* rn, float* box, uint32_t* nodeCount,
+                             uint32_t* next, uint8_t* keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = nearest[i];
+    const uint32_t mine = clusters[i];
+    if (nearest[j] != i) { next[i] = mine; keep[i] = 1; return; }
+    if (i > j) { next[i] = mine; keep[i] = 0; return; }
+    const uint32_t theirs = clusters[j];
+    const uint32_t k = atomicAdd(nodeCount, 1u);
+    const float* a = box + (size_t)ploc_slot(mine, nLeaves) * 6; const float* b = box + (size_t)ploc_slot(theirs, nLeaves) * 6;
+    float* o = box + (size_t)k * 6;
+    for (int c = 0; c < 3; ++c) { o[c] = __builtin_fminf(a[c], b[c]); o[3 + c] = __builtin_fmaxf(a[3 + c], b[3 + c]); }
+    RadixNode r; r.left = mine; r.right = theirs; r.first = 0u;
+    r.last = radix_span(rn, mine) + radix_span(rn, theirs) - 1u;          // span = last - first + 1 (the collapse reads nothing else of the range)
+    rn[k] = r;
+    next[i] = k; keep[i] = 1;
 }
 
 // nodes [first, first + count) of one BFS level, deepest level first

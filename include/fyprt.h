@@ -274,8 +274,10 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        trace kernel of frame N (asynchronous frames only overlap, of course; a blocking fyprt_render waits for its frame).
  * key 12: builder of the acceleration structure for the NEXT fyprt_upload_scene: 0 (default) host binned SAH + SAH-optimal
  *        collapse; 1 device LBVH (Morton sort, Karras radix tree, collapse, refit) — milliseconds instead of a fraction of a
- *        second for a million triangles, a slower tree to trace; falls back to the host builder if the tree gets deeper than
- *        31 wide levels.  Results stay exact either way (any valid tree finds the same closest hits but for exact-t ties).
+ *        second for a million triangles, a tree 1.65x slower to trace; 2 device PLOC (Morton sort, parallel locally-ordered
+ *        clustering with search radius FYPRT_PLOC_RADIUS = 16, collapse, refit) — the same build time, a tree 1.15x slower to
+ *        trace than the host builder's.  Both fall back to the host builder if the tree gets deeper than 31 wide levels.
+ *        Results stay exact in every case (any valid tree finds the same closest hits but for exact-t ties).
  * key 13: MEASUREMENT ONLY (tools/band_rate.py): 1 = a lone context skips ReSTIR Part 1 on its halo rows as a band does in halo-exchange
  *        mode, without anybody filling them — the cost of one band of an exchange-mode split; the image near the band border is not valid.
  * key 14: 1 = ReSTIR DI Part-2 setup fetches every neighbour record the spatial-reuse loop can possibly visit at once (the addresses
@@ -285,7 +287,7 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        the geometry test served from there; same results; measured slower as well (profiles/README.md r02).
  * key 15: ray kernel of the wavefront stages (techniques 0-6, ReSTIR GI): 1 = persistent waves with lane refill, 2 = one thread per ray,
  *        0 (default) = by tree size: one thread per ray below 65 536 triangles, where rays are too cheap for the refill machinery to pay.
- * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 12, 13: 0..1, keys 14, 15: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
+ * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 13: 0..1, keys 12, 14, 15: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
  * traversal must use too). */

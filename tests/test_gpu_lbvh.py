@@ -1,4 +1,5 @@
-"""the device builder (tuning key 12: Morton sort + Karras radix tree + wide collapse + refit, rt_lbvh.h).
+"""the device builders (tuning key 12; rt_lbvh.h): 1 = Morton sort + Karras radix tree, 2 = Morton sort + PLOC
+(parallel locally-ordered clustering), both followed by the wide collapse + refit.
 Same bars as for the host builder: structural invariants of the exported tree, bit-exact parity against the oracle traversing
 that exported tree, and the same picture as the host-built tree except for exact-t ties."""
 import numpy as np
@@ -10,15 +11,16 @@ from fypraytracer_amd import capi
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("builder", [1, 2])
 @pytest.mark.parametrize("name", ["hall_small", "cornell", "banana"])
-def test_device_built_tree(oracle_built, name):
+def test_device_built_tree(oracle_built, name, builder):
     from oraclelib import Oracle
     mk_scene, mk_cam = SCENES[name]
     sc, W, H = mk_scene(), 128, 80
     cam = mk_cam(W, H)
     ctx = capi.Context(0)
     ctx.resize(W, H)
-    ctx.set_tuning(12, 1)
+    ctx.set_tuning(12, builder)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
     bvh = ctx.export_bvh()
@@ -54,8 +56,9 @@ def test_device_built_tree(oracle_built, name):
     ctx.close(); host.close()
 
 
+@pytest.mark.parametrize("builder", [1, 2])
 @pytest.mark.parametrize("shape", ["nested", "exponential", "coincident"])
-def test_device_builder_on_pathological_input(oracle_built, shape):
+def test_device_builder_on_pathological_input(oracle_built, shape, builder):
     """Inputs that make a radix tree deep or degenerate: nested triangles sharing a corner, exponentially shrinking spacing (the
     Morton prefix changes at every level: the builder must fall back to the host one beyond 31 wide levels), many triangles
     with one and the same centroid (equal keys, told apart by position).  Whatever builder ends up being used, the exported
@@ -87,7 +90,7 @@ def test_device_builder_on_pathological_input(oracle_built, shape):
     cam.set_position((0.3, 0.2, 2.5))
     ctx = capi.Context(0)
     ctx.resize(W, H)
-    ctx.set_tuning(12, 1)
+    ctx.set_tuning(12, builder)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
     bvh = ctx.export_bvh()
@@ -101,3 +104,25 @@ def test_device_builder_on_pathological_input(oracle_built, shape):
     img, acc = ctx.readback()
     assert bits_equal(acc, orc.accum()).all() and np.array_equal(img, orc.image())
     ctx.close()
+
+
+def test_ploc_tree_is_cheaper_than_the_radix_tree():
+    """What PLOC is for: on a scene of some size its tree costs fewer node visits per ray than the radix tree's (the counters of
+    include/fyprt.h), while the pictures agree except for exact-t ties."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 256, 160
+    cam = mk_cam(W, H)
+    visits, images = {}, {}
+    for builder in (1, 2):
+        ctx = capi.Context(0)
+        ctx.resize(W, H)
+        ctx.set_tuning(12, builder)
+        ctx.upload_scene(sc)
+        ctx.set_camera(cam)
+        ctx.set_ray_counting(True)
+        stats = ctx.render(settings_for(capi.COSINE_WEIGHTED_SAMPLING))
+        visits[builder] = stats.node_visits / max(1, stats.rays)
+        images[builder] = ctx.readback()[1]
+        ctx.close()
+    assert visits[2] < visits[1], visits
+    assert bits_equal(images[1], images[2]).all(axis=-1).mean() > 0.97
