@@ -43,7 +43,10 @@ struct Builder {
     uint64_t forced = 0;
     std::vector<Node2> nodes; uint32_t maxDepth = 0; uint32_t maxLeaf; uint32_t depthLimit = kMaxDepthSafe;
     std::function<int32_t(const Prim*, uint32_t, uint32_t)> makeLeaf;   // (prims, count, depth) -> leaf ref
-    static constexpr int kBins = 16;
+    static constexpr int kMaxBins = 64;
+    int kBins = 16;                     // experiments: FYPRT_BVH_BINS
+    uint32_t sweepBelow = 0;            // nodes of fewer primitives than this try every split position (exact sweep SAH): FYPRT_BVH_SWEEP
+
     float nodeCost = 1.0f;              // SAH: cost of visiting a node relative to testing a triangle (experiments: FYPRT_BVH_NODE_COST)
 
     int32_t build(Prim* p, uint32_t first, uint32_t last, uint32_t depth, Box& outBox) {
@@ -56,17 +59,34 @@ struct Builder {
         const uint32_t balancedLevels = ceilLog2((count + maxLeaf - 1) / maxLeaf);
         const bool mustBalance = depth + balancedLevels + 1 >= depthLimit;
         if (mustBalance && count > maxLeaf) ++forced;
-        if (count > 1 && !mustBalance) {
+        bool swept = false;
+        if (count > 1 && !mustBalance && count < sweepBelow) {
+            std::vector<float> ra(count);
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(cb.hi[axis] > cb.lo[axis])) continue;
+                std::sort(p + first, p + last, [axis](const Prim& a, const Prim& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id); });
+                Box acc;
+                for (uint32_t i = count - 1; i > 0; --i) { acc.grow(p[first + i].b); ra[i] = acc.area(); }
+                acc = Box();
+                for (uint32_t i = 0; i + 1 < count; ++i) {
+                    acc.grow(p[first + i].b);
+                    const float cost = acc.area() * (float)(i + 1) + ra[i + 1] * (float)(count - i - 1);
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = (int)(i + 1); }
+                }
+            }
+            swept = bestAxis >= 0;
+        }
+        if (count > 1 && !mustBalance && !swept) {
             for (int axis = 0; axis < 3; ++axis) {
                 const float cmin = cb.lo[axis], cmax = cb.hi[axis];
                 if (!(cmax > cmin)) continue;
-                Box bb[kBins]; uint32_t bc[kBins] = {0};
+                Box bb[kMaxBins]; uint32_t bc[kMaxBins] = {0};
                 const float scale = (float)kBins / (cmax - cmin);
                 for (uint32_t i = first; i < last; ++i) {
                     int b = std::min(kBins - 1, std::max(0, (int)((p[i].c[axis] - cmin) * scale)));
                     bc[b]++; bb[b].grow(p[i].b);
                 }
-                float rightArea[kBins]; uint32_t rightCount[kBins]; Box acc; uint32_t n = 0;
+                float rightArea[kMaxBins]; uint32_t rightCount[kMaxBins]; Box acc; uint32_t n = 0;
                 for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); n += bc[b]; rightArea[b] = acc.area(); rightCount[b] = n; }
                 acc = Box(); n = 0;
                 for (int b = 0; b < kBins - 1; ++b) {
@@ -84,7 +104,11 @@ struct Builder {
             if (count == 1 || leafCost <= splitCost) { maxDepth = std::max(maxDepth, depth); return makeLeaf(p + first, count, depth); }
         }
         uint32_t mid;
-        if (bestAxis >= 0) {
+        if (swept) {
+            const int axis = bestAxis;
+            std::sort(p + first, p + last, [axis](const Prim& a, const Prim& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id); });
+            mid = first + (uint32_t)bestBin;
+        } else if (bestAxis >= 0) {
             const float cmin = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cmin);
             Prim* m = std::partition(p + first, p + last, [&](const Prim& q) {
                 return std::min(kBins - 1, std::max(0, (int)((q.c[bestAxis] - cmin) * scale))) <= bestBin; });
@@ -271,6 +295,8 @@ static void BuildWithDepthBound(const fyprt_vertex* verts, const uint8_t* tris, 
         MeshOut& o = mo[m];
         Builder b; b.maxLeaf = 4; b.depthLimit = kMaxDepth - leafDepth[m];
         if (const char* e = std::getenv("FYPRT_BVH_NODE_COST")) b.nodeCost = (float)std::atof(e);
+        if (const char* e = std::getenv("FYPRT_BVH_BINS")) b.kBins = std::min(Builder::kMaxBins, std::max(2, std::atoi(e)));
+        if (const char* e = std::getenv("FYPRT_BVH_SWEEP")) b.sweepBelow = (uint32_t)std::max(0, std::atoi(e));
         b.makeLeaf = [&](const Prim* p, uint32_t count, uint32_t) -> int32_t {
             const uint32_t first = (uint32_t)o.tris.size();
             for (uint32_t i = 0; i < count; ++i) {

@@ -1,0 +1,152 @@
+"""State-machine parity: seeded random SEQUENCES of boundary calls — frames of any technique with random settings, camera moves that
+keep the previous matrices (Camera::OnUpdate) and ones that reset them (SetPosition), frame-index resets, resizes, scene
+replacement, row bands with a halo, blocking and asynchronous frames, every tuning key that must not change a result — mirrored on
+the oracle (walking the product's exported tree), compared bit for bit after every frame.  The single-feature tests start each case
+from a fresh context; this one catches state that leaks from one call into the next (history of another technique or scene, stale
+rows, a queue parity, a half-applied tuning change).  Mirrors what Renderer::Render sees from the application's main loop
+(WalnutApp.cpp:878-910) over a session."""
+import numpy as np
+import pytest
+
+from common import SCENES, bits_equal, struct_equal
+from fypraytracer_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(64, 48), (80, 40), (48, 64)]
+NEUTRAL_KEYS = {0: [0, 1, 2], 1: [0, 1], 2: [0, 1, 3], 3: [0, 1], 4: [0, 16, 128], 5: [0, 8, 48], 6: [0, 16], 7: [0, 16], 9: [0, 1, 4], 10: [0, 8], 11: [0, 1], 14: [0, 1, 2],
+                15: [0, 1, 2]}
+
+
+def _random_settings(rng):
+    tech = int(rng.integers(0, 9))
+    return capi.Settings(technique=tech, light_bounces=int(rng.integers(1, 4)), sample_count=int(rng.integers(1, 3)),
+                         sky_color=tuple(float(x) for x in rng.uniform(0.0, 0.4, 3)), light_candidate_count=int(rng.integers(1, 9)),
+                         use_temporal_reuse=int(rng.integers(0, 2)), use_spatial_reuse=int(rng.integers(0, 2)),
+                         temporal_history_limit=int(rng.integers(1, 6)), spatial_neighbor_num=int(rng.integers(0, 6)),
+                         spatial_neighbor_radius=int(rng.integers(1, 31)), rand_seed=int(rng.integers(0, 1 << 30)))
+
+
+class Mirror:
+    """the product context and its oracle twin, kept in the same state"""
+
+    def __init__(self, rng):
+        from oraclelib import Oracle
+        self.Oracle, self.rng = Oracle, rng
+        self.ctx = capi.Context(0)
+        self.W, self.H = SIZES[0]
+        self.ctx.resize(self.W, self.H)
+        self.orc = None
+        self.rows, self.halo = None, 0
+        self.load("hall_small")
+
+    def load(self, name):
+        mk_scene, mk_cam = SCENES[name]
+        self.name, self.sc, self.mk_cam = name, mk_scene(), mk_cam
+        self.cam = mk_cam(self.W, self.H)
+        # The oracle has no "replace the scene" call: its twin starts over with empty per-pixel buffers, so the product does too (a
+        # resize zero-fills them; a band that still fits survives it).  What a replaced scene does to history that is NOT cleared is
+        # the subject of test_scene_replaced_with_fewer_lights... in tests/test_gpu_moving_camera.py.
+        self.ctx.resize(self.W, self.H)
+        self.ctx.upload_scene(self.sc)
+        self.ctx.set_camera(self.cam)
+        self.bvh = self.ctx.export_bvh()
+        self._new_oracle()
+
+    def _new_oracle(self):
+        if self.orc is not None:
+            self.orc.close()
+        self.orc = self.Oracle(self.sc, self.W, self.H)
+        self.orc.set_camera(self.cam)
+        self.orc.use_product_bvh(self.bvh)
+
+    def resize(self, W, H):
+        self.W, self.H = W, H
+        self.ctx.resize(W, H)
+        self.ctx.set_rows(0, H, 0)                         # (a band that still fits would survive the resize)
+        self.cam = self.mk_cam(W, H)
+        self.ctx.set_camera(self.cam)
+        self.rows, self.halo = None, 0
+        self._new_oracle()
+
+    def frame(self, st, asynchronous):
+        if asynchronous:
+            self.ctx.render_async(st)
+            self.ctx.synchronize()
+        else:
+            self.ctx.render(st)
+        self.orc.render(st, rows=self.rows, halo=self.halo)
+        y0, y1 = self.rows if self.rows else (0, self.H)
+        img, acc = self.ctx.readback()
+        ok = bits_equal(acc[y0:y1], self.orc.accum()[y0:y1]).all(axis=-1)
+        assert ok.all(), f"{(~ok).sum()} accumulation pixels differ"
+        assert np.array_equal(img[y0:y1], self.orc.image()[y0:y1])
+        sl = slice(y0 * self.W, y1 * self.W)
+        # (the per-pixel techniques own no buffer besides accumulation and image: Renderer.cu:87-166)
+        bufs = [] if st.technique < capi.RESTIR_DI else [capi.BUF_PAYLOAD, capi.BUF_DEPTH, capi.BUF_DI_PREV if st.technique == capi.RESTIR_DI else capi.BUF_GI_PREV]
+        for b in bufs:
+            g, o = self.ctx.read_buffer(b)[sl], self.orc.read_buffer(b)[sl]
+            e = struct_equal(g, o) if g.dtype.names else bits_equal(g, o)
+            assert e.all(), f"buffer {b}: {(~e).sum()} records differ"
+
+    def close(self):
+        self.orc.close()
+        self.ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_random_call_sequences_against_the_oracle(oracle_built, seed):
+    rng = np.random.default_rng(1000 + seed)
+    m = Mirror(rng)
+    log = []
+    try:
+        for step in range(26):
+            op = rng.choice(["frame", "frame", "frame", "frames", "pose", "teleport", "reset", "resize", "scene", "band", "tuning"])
+            if op in ("frame", "frames"):
+                st = _random_settings(rng)
+                n = 1 if op == "frame" else 3
+                log.append(f"{op} tech {st.technique} T{st.use_temporal_reuse} S{st.use_spatial_reuse} r{st.spatial_neighbor_radius}")
+                for k in range(n):
+                    st.rand_seed = int(rng.integers(0, 1 << 30))
+                    if k:
+                        m.cam.on_update(0.05, "W" if k == 1 else "DQ", (float(rng.uniform(-80, 80)), float(rng.uniform(-40, 40))))
+                        m.ctx.set_camera(m.cam); m.orc.set_camera(m.cam)
+                    m.frame(st, asynchronous=bool(rng.integers(0, 2)))
+            elif op == "pose":
+                keys = "".join(rng.choice(list("WASDQE"), size=int(rng.integers(0, 3))))
+                m.cam.on_update(0.05, keys, (float(rng.uniform(-150, 150)), float(rng.uniform(-90, 90))))
+                m.ctx.set_camera(m.cam); m.orc.set_camera(m.cam)
+                log.append(f"pose {keys}")
+            elif op == "teleport":
+                p = np.asarray(m.cam.position, np.float64) + rng.uniform(-0.3, 0.3, 3)
+                m.cam.set_position(tuple(float(x) for x in p))
+                m.ctx.set_camera(m.cam); m.orc.set_camera(m.cam)
+                log.append("teleport")
+            elif op == "reset":
+                m.ctx.reset_frame_index(); m.orc.reset_frame_index()
+                log.append("reset")
+            elif op == "resize":
+                W, H = SIZES[int(rng.integers(0, len(SIZES)))]
+                m.resize(W, H)
+                log.append(f"resize {W}x{H}")
+            elif op == "scene":
+                m.load("cornell" if m.name != "cornell" else "hall_small")
+                log.append(f"scene {m.name}")
+            elif op == "band":
+                if rng.integers(0, 3) == 0:
+                    m.rows, m.halo = None, 0
+                    m.ctx.set_rows(0, m.H, 0)
+                else:
+                    y0 = int(rng.integers(0, m.H - 8)); y1 = int(rng.integers(y0 + 4, m.H + 1)); halo = int(rng.choice([0, 30]))
+                    m.rows, m.halo = (y0, y1), halo
+                    m.ctx.set_rows(y0, y1, halo)
+                log.append(f"band {m.rows} halo {m.halo}")
+            else:
+                key = int(rng.choice(list(NEUTRAL_KEYS)))
+                val = int(rng.choice(NEUTRAL_KEYS[key]))
+                m.ctx.set_tuning(key, val)
+                log.append(f"tuning {key}={val}")
+    except AssertionError as e:
+        raise AssertionError(f"after {log}: {e}") from None
+    finally:
+        m.close()
