@@ -760,7 +760,9 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
     }
     if (c->countRays && phase != 2) HIPCHK(c, hipMemsetAsync(c->rayCounter.p, 0, 256, c->stream));
     // frame 1 (or toAccumulate == false): the accumulator starts from zero (Renderer.cu:50-51) — on `stream`, which owns it
-    if (c->frameIndex == 1 && phase != 2) HIPCHK(c, hipMemsetAsync(c->accum.p + (size_t)c->rowBegin * c->W, 0, (size_t)(c->rowEnd - c->rowBegin) * c->W * sizeof(float4), c->stream));
+    // (the whole buffer, as the reference does, not just this context's rows: a band moved later with fyprt_set_rows must not find the
+    // sums of an earlier accumulation in its new rows)
+    if (c->frameIndex == 1 && phase != 2) HIPCHK(c, hipMemsetAsync(c->accum.p, 0, c->accum.bytes(), c->stream));
     const uint32_t tilesX = (c->W + 15u) / 16u;
     fr.tileOrder = (uint32_t)c->tuning[0];
     fr.p1Mode = wavefront ? 1u : 0u;
