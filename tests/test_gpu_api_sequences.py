@@ -1,6 +1,7 @@
 """State-machine parity: seeded random SEQUENCES of boundary calls — frames of any technique with random settings, camera moves that
 keep the previous matrices (Camera::OnUpdate) and ones that reset them (SetPosition), frame-index resets, resizes, scene
-replacement, row bands with a halo, blocking and asynchronous frames, every tuning key that must not change a result — mirrored on
+replacement (with any of the three tree builders), row bands with a halo, blocking and asynchronous frames, the instrumented kernel
+variants, every tuning key that must not change a result — mirrored on
 the oracle (walking the product's exported tree), compared bit for bit after every frame.  The single-feature tests start each case
 from a fresh context; this one catches state that leaks from one call into the next (history of another technique or scene, stale
 rows, a queue parity, a half-applied tuning change).  Mirrors what Renderer::Render sees from the application's main loop
@@ -48,6 +49,7 @@ class Mirror:
         # resize zero-fills them; a band that still fits survives it).  What a replaced scene does to history that is NOT cleared is
         # the subject of test_scene_replaced_with_fewer_lights... in tests/test_gpu_moving_camera.py.
         self.ctx.resize(self.W, self.H)
+        self.ctx.set_tuning(12, int(self.rng.integers(0, 3)))      # host SAH / device radix tree / device PLOC: the oracle walks whatever was built
         self.ctx.upload_scene(self.sc)
         self.ctx.set_camera(self.cam)
         self.bvh = self.ctx.export_bvh()
@@ -94,14 +96,14 @@ class Mirror:
         self.ctx.close()
 
 
-@pytest.mark.parametrize("seed", list(range(1, 11)))
+@pytest.mark.parametrize("seed", list(range(1, 17)))
 def test_random_call_sequences_against_the_oracle(oracle_built, seed):
     rng = np.random.default_rng(1000 + seed)
     m = Mirror(rng)
     log = []
     try:
         for step in range(26):
-            op = rng.choice(["frame", "frame", "frame", "frames", "pose", "teleport", "reset", "resize", "scene", "band", "tuning"])
+            op = rng.choice(["frame", "frame", "frame", "frames", "pose", "teleport", "reset", "resize", "scene", "band", "tuning", "counting"])
             if op in ("frame", "frames"):
                 st = _random_settings(rng)
                 n = 1 if op == "frame" else 3
@@ -141,6 +143,10 @@ def test_random_call_sequences_against_the_oracle(oracle_built, seed):
                     m.rows, m.halo = (y0, y1), halo
                     m.ctx.set_rows(y0, y1, halo)
                 log.append(f"band {m.rows} halo {m.halo}")
+            elif op == "counting":
+                on = bool(rng.integers(0, 2))
+                m.ctx.set_ray_counting(on)                   # the instrumented kernel variants compute the same pixels
+                log.append(f"counting {on}")
             else:
                 key = int(rng.choice(list(NEUTRAL_KEYS)))
                 val = int(rng.choice(NEUTRAL_KEYS[key]))
