@@ -128,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_group_synchronize", "fyprt_comm_unique_id", "fyprt_comm_init_rank", "fyprt_comm_set_rows", "fyprt_comm_set_halo_mode", "fyprt_comm_render",
     "fyprt_comm_gather", "fyprt_comm_destroy", "fyprt_render_part", "fyprt_balance_rows", "fyprt_last_frame_ms", "fyprt_halo_plan",
     "fyprt_set_object_vertices", "fyprt_update_transforms", "fyprt_compare_image",
-    "fyprt_set_row_stripes", "fyprt_group_set_interleave", "fyprt_comm_set_interleave",
+    "fyprt_set_row_stripes", "fyprt_group_set_interleave", "fyprt_comm_set_interleave", "fyprt_selftest_math",
 ]
 
 
@@ -189,6 +189,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_group_set_interleave.argtypes = [vp, u32]
     lib.fyprt_comm_set_interleave.argtypes = [vp, u32]
     lib.fyprt_set_row_stripes.argtypes = [vp, u32, u32, u32]
+    lib.fyprt_selftest_math.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(u32)]
     lib.fyprt_group_render.argtypes = [vp, C.POINTER(Settings)]
     lib.fyprt_group_gather.argtypes = [vp, C.c_int]
     lib.fyprt_group_synchronize.argtypes = [vp]
@@ -300,6 +301,12 @@ class Context:
 
     def set_rows(self, row_begin, row_end, halo_rows=0):
         self._check(self.lib.fyprt_set_rows(self.h, row_begin, row_end, halo_rows))
+
+    def selftest_math(self):
+        """(mismatch counts, first offending argument bits) of the lean sqrt / 1/x / 1/sqrt(x) over all 2^32 arguments each."""
+        n, f = (C.c_uint64 * 3)(), (C.c_uint32 * 3)()
+        self._check(self.lib.fyprt_selftest_math(self.h, n, f))
+        return list(n), list(f)
 
     def set_row_stripes(self, stripe_rows, parts=1, part=0):
         """Interleaved split of the per-pixel techniques: this context renders stripes part, part + parts, ... (0 rows = off)."""

@@ -1015,6 +1015,27 @@ int fyprt_readback(fyprt_context* c, uint32_t* rgba8, float* accum4) {
     return FYPRT_OK;
 }
 
+// The lean correctly rounded sqrt / reciprocal / reciprocal square root of rt_math.h against the compiler's sequences on all 2^32
+// arguments each (a few milliseconds).  mismatches[3] / first_bad[3] in the order sqrt, 1/x, 1/sqrt(x); all zero on a sound build.
+int fyprt_selftest_math(fyprt_context* c, uint64_t* mismatches3, uint32_t* first_bad3) {
+    if (!c || !mismatches3) return FYPRT_EINVAL;
+    if (c->hostOnly) return c->fail(FYPRT_ESTATE, "fyprt_selftest_math needs a device");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
+    DevBuf<unsigned long long> counts; DevBuf<uint32_t> first;
+    HIPCHK(c, counts.alloc(3)); HIPCHK(c, first.alloc(3));
+    hipError_t e = hipMemsetAsync(counts.p, 0, 24, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(first.p, 0xFF, 12, c->stream);
+    for (int w = 0; w < 3 && e == hipSuccess; ++w) { hipLaunchKernelGGL(k_math_selftest, dim3((uint32_t)c->numCUs * 16u), dim3(256), 0, c->stream, w, counts.p, first.p); e = hipGetLastError(); }
+    unsigned long long hc[3] = {0, 0, 0}; uint32_t hf[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(hc, counts.p, 24, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hf, first.p, 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    counts.release(); first.release();
+    HIPCHK(c, e);
+    for (int w = 0; w < 3; ++w) { mismatches3[w] = hc[w]; if (first_bad3) first_bad3[w] = hf[w]; }
+    return FYPRT_OK;
+}
+
 // MisUtils::ComputeMSE / ComputePSNR (MisUtils.cpp:118-157) of the frame on the device against a host reference image (the benchmark
 // workflow of WalnutApp.cpp:826-876 without reading the frame back): RGB channels of the 8-bit images, this context's rows.
 int fyprt_compare_image(fyprt_context* c, const uint32_t* reference_rgba8, int flip_reference_rows, double* mse, double* psnr) {

@@ -38,8 +38,42 @@ RT_DEV f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
 RT_DEV f3 rsub(float s, f3 a) { return mk3(s - a.x, s - a.y, s - a.z); }          // float - vec3
 RT_DEV float dot(f3 a, f3 b) { float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z; return (tx + ty) + tz; }
 RT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-RT_DEV float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
-RT_DEV f3 normalize(f3 a) { float inv = 1.0f / __builtin_sqrtf(dot(a, a)); return a * inv; }
+
+// ---- correctly rounded sqrt(x), 1/x and 1/sqrt(x) in fewer instructions
+// hipcc's correctly rounded sqrtf is 16 VALU instructions (denormal pre-scaling, v_sqrt_f32, a test of both neighbours through
+// two compares, class fix-up) and its 1/x is 11 (v_div_scale x 2, v_rcp, five fma, v_div_fmas, v_div_fixup), plus the wait states
+// between each compare and its v_cndmask.  For an argument whose magnitude is in [2^-96, 2^96) — no intermediate can leave the normal range —
+// the sequences below give THE SAME BITS in 8 and 5 instructions: the hardware estimate (v_rsq_f32 / v_rcp_f32, 1 ulp) refined with
+// fused residuals (Markstein).  "The same bits" is not an argument but a measurement: fyprt_selftest_math compares each of the three
+// functions with the compiler's sequence on ALL 2^32 arguments (tests/test_gpu_math.py; 0 mismatches on gfx950).  Everything outside
+// the range (zero, denormals, huge, inf, NaN, negative sqrt arguments) takes the compiler's sequence.  The light-tree importance
+// (nine normalisations per cluster) and every normalize() / length() of the shading code go through these.
+#ifdef RT_NO_LEAN_MATH       // A/B builds (tools/build_variant.sh): the compiler's sequences everywhere
+RT_DEV bool lean_range(float) { return false; }
+#else
+RT_DEV bool lean_range(float x) { return (__float_as_uint(x) - 0x0F800000u) < (0x6F800000u - 0x0F800000u); }      // 2^-96 <= x < 2^96 (positive, finite)
+#endif
+RT_DEV float lean_sqrt(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g); h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
+RT_DEV float lean_rcp(float s) {
+    float y = __builtin_amdgcn_rcpf(s);
+    float e = __builtin_fmaf(-s, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    e = __builtin_fmaf(-s, y, 1.0f);
+    return __builtin_fmaf(e, y, y);
+}
+RT_DEV float sqrt_exact(float x) { return lean_range(x) ? lean_sqrt(x) : __builtin_sqrtf(x); }                                 // == sqrtf(x)
+RT_DEV float rcp_exact(float x) { return lean_range(__builtin_fabsf(x)) ? lean_rcp(x) : 1.0f / x; }                           // == 1.0f / x
+RT_DEV float rsqrt_exact(float x) { return lean_range(x) ? lean_rcp(lean_sqrt(x)) : 1.0f / __builtin_sqrtf(x); }              // == 1.0f / sqrtf(x), two roundings
+
+RT_DEV float length(f3 a) { return sqrt_exact(dot(a, a)); }
+RT_DEV f3 normalize(f3 a) { float inv = rsqrt_exact(dot(a, a)); return a * inv; }
 RT_DEV f3 reflect(f3 I, f3 N) { return I - N * dot(N, I) * 2.0f; }
 RT_DEV f3 mix(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
 RT_DEV bool finitef(float x) { return __builtin_fabsf(x) <= 3.402823466e+38f; }   // false for NaN / inf
@@ -69,6 +103,14 @@ __constant__ double kAsinPoly[11] = {0x1.c88ae5be4eda1p-6, -0x1.bf334244335c0p-8
                                      0x1.1c0cd5e2c5a38p-6, 0x1.6e8f421105f62p-6, 0x1.f1c6fee482ca3p-6, 0x1.6db6dbab38ae8p-5, 0x1.33333333018c8p-4,
                                      0x1.55555555555bcp-3};
 __constant__ double kPiSplit[4] = {0x1.45f306dc9c883p-1, 0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54, 0x1.921fb54442d18p+1};   // 2/pi, pi/2 hi, pi/2 lo, pi
+// fma(a, b, c) with a wave-uniform c (a coefficient from constant memory) as the instruction's scalar operand.  Left to itself the
+// compiler turns `p = fma(p, z, c)` into v_fmac_f64 and first copies c from its SGPR pair into the accumulator with two v_mov_b32 —
+// three VALU issues per Horner step instead of one (acos_f: 77 -> 55 instructions).  Same operation, same bits.
+RT_DEV double fma_uniform_c(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
 RT_DEV void sincos_f(float xf, float& s_out, float& c_out) {
     // valid for xf in [0, 2*pi + eps] (2*pi*u) and small positive angles; Cody–Waite by pi/2
     const double x = (double)xf;
@@ -79,11 +121,11 @@ RT_DEV void sincos_f(float xf, float& s_out, float& c_out) {
     const double z = r * r;
     double sp = kSinPoly[0];
 #pragma unroll
-    for (int i = 1; i < 6; ++i) sp = __builtin_fma(sp, z, kSinPoly[i]);
+    for (int i = 1; i < 6; ++i) sp = fma_uniform_c(sp, z, kSinPoly[i]);
     const double sr = __builtin_fma(-(r * z), sp, r);
     double cp = kCosPoly[0];
 #pragma unroll
-    for (int i = 1; i < 7; ++i) cp = __builtin_fma(cp, z, kCosPoly[i]);
+    for (int i = 1; i < 7; ++i) cp = fma_uniform_c(cp, z, kCosPoly[i]);
     const double cr = __builtin_fma(-z, cp, 1.0);
     const int q = k & 3;
     const double s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
@@ -95,7 +137,7 @@ RT_DEV float pow5_f(float x) { const double d = (double)x; const double d2 = d *
 RT_DEV double asin_kernel(double z) {   // (asin(sqrt z)/sqrt z - 1)/z on [0, 0.25]; tools/gen_detmath_coeffs.py
     double p = kAsinPoly[0];
 #pragma unroll
-    for (int i = 1; i < 11; ++i) p = __builtin_fma(p, z, kAsinPoly[i]);
+    for (int i = 1; i < 11; ++i) p = fma_uniform_c(p, z, kAsinPoly[i]);
     return p;
 }
 RT_DEV float acos_f(float xf) {

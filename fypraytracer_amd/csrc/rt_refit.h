@@ -159,4 +159,20 @@ __global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32
     nodeBox[(size_t)node * 2 + 1] = make_float4(nb.hi[0], nb.hi[1], nb.hi[2], 0.0f);
 }
 
+// fyprt_selftest_math: the three lean functions of rt_math.h against the compiler's correctly rounded sequences on every one of the
+// 2^32 binary32 arguments.  counts[which] = number of arguments with different result bits (NaN == NaN), first[which] = the smallest such.
+__global__ void k_math_selftest(int which, unsigned long long* counts, uint32_t* first) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t bad = 0, firstBad = 0xFFFFFFFFu;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        float a, b;
+        if (which == 0) { a = sqrt_exact(x); b = __builtin_sqrtf(x); }
+        else if (which == 1) { a = rcp_exact(x); b = 1.0f / x; }
+        else { a = rsqrt_exact(x); b = 1.0f / __builtin_sqrtf(x); }
+        if (!(__float_as_uint(a) == __float_as_uint(b) || (a != a && b != b))) { ++bad; firstBad = (uint32_t)i < firstBad ? (uint32_t)i : firstBad; }
+    }
+    if (bad) { atomicAdd(counts + which, (unsigned long long)bad); atomicMin(first + which, firstBad); }
+}
+
 }  // namespace rt

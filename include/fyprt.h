@@ -307,6 +307,10 @@ int fyprt_update_transforms(fyprt_context* ctx, const uint32_t* mesh_indices, co
  * device (exact integer sums: equals the host routine bit for bit); `flip_reference_rows` reads the reference vertically flipped as
  * ComputeMSE reads its BMP original.  The benchmark workflow of WalnutApp.cpp:826-876 without a read-back.  `psnr` may be NULL. */
 int fyprt_compare_image(fyprt_context* ctx, const uint32_t* reference_rgba8, int flip_reference_rows, double* mse, double* psnr);
+/* Self-test of the arithmetic contract: the library's short correctly rounded sqrt / 1/x / 1/sqrt(x) sequences (rt_math.h) against the
+ * compiler's IEEE sequences on ALL 2^32 binary32 arguments each.  mismatches[3] (and, optionally, the smallest offending argument's bits)
+ * in the order sqrt, reciprocal, reciprocal square root; all zero on a sound build.  New (no reference counterpart). */
+int fyprt_selftest_math(fyprt_context* ctx, uint64_t* mismatches3, uint32_t* first_bad3 /* may be NULL */);
 
 /* ================================================================================================= multi-GPU
  * The reference renders on one GPU (Renderer.cu:13-284); there is no reference interface for this section.  It splits ONE
