@@ -200,7 +200,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     const size_t n = (size_t)w * h;
     HIPCHK(c, c->accum.alloc(n)); HIPCHK(c, c->image.alloc(n)); HIPCHK(c, c->payload.alloc(n)); HIPCHK(c, c->depth.alloc(n));
     HIPCHK(c, c->normalA.alloc(n)); HIPCHK(c, c->normalB.alloc(n));
-    HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n)); HIPCHK(c, c->giHot.alloc(n));
+    HIPCHK(c, c->di.alloc(n)); HIPCHK(c, c->diPrev.alloc(n)); HIPCHK(c, c->gi.alloc(n)); HIPCHK(c, c->giPrev.alloc(n)); HIPCHK(c, c->giHot.alloc(n * 4));
     HIPCHK(c, hipMemsetAsync(c->giHot.p, 0, c->giHot.bytes(), c->stream));
     HIPCHK(c, c->drec.alloc(n)); HIPCHK(c, c->dprevA.alloc(n)); HIPCHK(c, c->dprevB.alloc(n));
     HIPCHK(c, hipMemsetAsync(c->drec.p, 0, c->drec.bytes(), c->stream)); HIPCHK(c, hipMemsetAsync(c->dprevA.p, 0, c->dprevA.bytes(), c->stream));

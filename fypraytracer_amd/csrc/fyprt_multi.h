@@ -55,7 +55,7 @@ std::vector<XBuf> exchange_buffers(fyprt_context* c, int tech, int kind) {
         else v.push_back({c->dprevFlip ? (void*)c->dprevB.p : (void*)c->dprevA.p, sizeof(DIRec)});
     } else {
         if (kind == 0) {
-            v.push_back({c->gi.p, sizeof(GIRes)}); v.push_back({c->giHot.p, sizeof(float4)});            // Part 2 reads a neighbour's reservoir + hot record
+            v.push_back({c->gi.p, sizeof(GIRes)}); v.push_back({c->giHot.p, 4 * sizeof(float4)});        // Part 2 reads a neighbour's 64-byte record; the reservoir only of the finally selected sample
             v.push_back({c->normalFlip ? (void*)c->normalA.p : (void*)c->normalB.p, sizeof(f2)});      // this frame's normals: next frame's history normals
         } else v.push_back({c->giPrev.p, sizeof(GIRes)});          // (last frame's normals of the halo rows arrived with last frame's Part-1 exchange)
     }

@@ -53,8 +53,11 @@ static_assert(sizeof(DIRec) == 32, "layout");
 struct DevFrame {
     float4* accum; uint32_t* image; Payload* payload; float* depth; f2* normalPrev; f2* normalCur;
     DIRes* di; DIRes* diPrev; GIRes* gi; GIRes* giPrev;
-    float4* giHot;   // ReSTIR GI: what Part 2's neighbour test reads about a pixel in ONE 16-byte record — primary hit distance, octahedral normal,
-                     // |Lo| of its Part-1 reservoir — instead of three gathers into payload (40 B), normal (8 B) and reservoir (72 B) arrays
+    float4* giHot;   // ReSTIR GI: what Part 2 reads about a NEIGHBOUR, one aligned 64-byte record (4 x float4) per pixel, written by Part 1:
+                     //   [0] primary hit distance, octahedral normal, |Lo| of the Part-1 reservoir — the 16 bytes the acceptance test needs
+                     //   [1] visible point, M   [2] sample point, weightSum   [3] octahedral sample normal — what a merge needs
+                     // so a rejected neighbour costs one 16-byte gather and an accepted one the rest of the same cache line, instead of
+                     // gathers into the payload (40 B), normal (8 B) and reservoir (80 B, two or three lines) arrays
     DIRec* drec; const DIRec* dprevRead; DIRec* dprevWrite;   // DI: this frame's records; previous frame's (read) / next frame's history (write)
     uint32_t W, H, frameIndex, rowBegin, rowEnd, tileOrder;
     uint32_t histBegin, histEnd;   // rows whose ReSTIR history (previous frame) this context holds: the band it rendered last frame

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_gi_primary(DevScene sc, DevCamera ca
         if (finished) {
             GIRes R; gi_reset(R);
             fr.gi[i] = R; fr.depth[i] = pp.hitDistance;
-            fr.giHot[i] = make_float4(pp.hitDistance, ncur.x, ncur.y, 0.0f);       // an empty reservoir: |Lo| = 0
+            fr.giHot[(size_t)i * 4] = make_float4(pp.hitDistance, ncur.x, ncur.y, 0.0f);       // an empty reservoir: |Lo| = 0 (the rest of the record is never read then)
             if (inBand) epilogue(fr, i, rgb1(finalColor));
         } else live = true;
     }
@@ -501,7 +501,14 @@ RT_DEV bool gi1_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
         }
     }
     fr.gi[i] = R;
-    { const f2 n = oct_encode(nrm3(pp)); fr.giHot[i] = make_float4(pp.hitDistance, n.x, n.y, length(lo3(R.s))); }   // == payload.hitDistance, normalCur, |Lo| as Part 2 would compute them
+    {   // the neighbour record of Part 2 (DevFrame::giHot): payload.hitDistance, normalCur, |Lo| as Part 2 would compute them + what a merge reads
+        const f2 n = oct_encode(nrm3(pp));
+        float4* q = fr.giHot + (size_t)i * 4;
+        q[0] = make_float4(pp.hitDistance, n.x, n.y, length(lo3(R.s)));
+        q[1] = make_float4(R.s.vp[0], R.s.vp[1], R.s.vp[2], __int_as_float((int)R.M));
+        q[2] = make_float4(R.s.sp[0], R.s.sp[1], R.s.sp[2], R.wSum);
+        q[3] = make_float4(R.s.sn[0], R.s.sn[1], 0.0f, 0.0f);
+    }
     toPart2 = (y >= fr.rowBegin && y < fr.rowEnd);          // replaces the reference's image sentinel (R.cu:2746-2750 / :2787): Part 2 runs on a list
     return false;
 }
@@ -544,15 +551,17 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     if (st.useSpatial) {
         for (; n < st.numNeighbors; ++n) {
             const uint32_t ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
-            const float4 hot = fr.giHot[ni];                                 // depth, normal, |Lo| of the neighbour: one 16-byte gather decides
+            const float4* nq = fr.giHot + (size_t)ni * 4;
+            const float4 hot = nq[0];                                        // depth, normal, |Lo| of the neighbour: one 16-byte gather decides
             const float nd = hot.x, pdp = pp.hitDistance, nlen = hot.w;
             f2 nnrm; nnrm.x = hot.y; nnrm.y = hot.z;
             if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(nrm3(pp), oct_decode(nnrm)) < 0.906 || nlen == 0.0f) continue;
-            const GIRes N = fr.gi[ni];                                       // accepted: now the reservoir
-            Z += N.M;
-            f2 sne; sne.x = N.s.sn[0]; sne.y = N.s.sn[1];
+            const float4 n1 = nq[1], n2 = nq[2], n3 = nq[3];                 // accepted: the rest of the SAME 64-byte line (not the 80-byte reservoir, two or three lines away)
+            const uint32_t NM = (uint32_t)__float_as_int(n1.w); const float NwSum = n2.w;
+            Z += NM;
+            f2 sne; sne.x = n3.x; sne.y = n3.y;
             const f3 sn = oct_decode(sne);
-            const f3 nvp = mk3(N.s.vp[0], N.s.vp[1], N.s.vp[2]), nsp = mk3(N.s.sp[0], N.s.sp[1], N.s.sp[2]);
+            const f3 nvp = xyz(n1), nsp = xyz(n2);
             const f3 dQ = normalize(nvp - nsp);
             const float cosQ = dot(sn, dQ);
             const f3 dR = normalize(rvp - nsp);
@@ -566,7 +575,7 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             out = ray_visible(nsp, dR, i, distR, tol);
             S[0] = make_float4(__int_as_float((int)src), spdf, Wr, wSum);
             S[1] = make_float4(__int_as_float((int)M), __int_as_float((int)seed), __int_as_float((int)n), __int_as_float((int)Z));
-            S[2] = make_float4(__int_as_float((int)ni), pdf, N.wSum, __int_as_float((int)N.M));
+            S[2] = make_float4(__int_as_float((int)ni), pdf, NwSum, __int_as_float((int)NM));
             if (rvpChanged) S[3] = f3f(rvp, 0.0f);
             S[4] = f3f(nvp, 0.0f);
             return true;
