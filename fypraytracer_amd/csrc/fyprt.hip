@@ -68,6 +68,7 @@ struct fyprt_context {
     DevBuf<float4> accum; DevBuf<uint32_t> image; DevBuf<Payload> payload; DevBuf<float> depth; DevBuf<f2> normalA, normalB;
     DevBuf<DIRes> di, diPrev; DevBuf<GIRes> gi, giPrev; DevBuf<float4> giHot; bool normalFlip = false;
     DevBuf<DIRec> drec, dprevA, dprevB; bool dprevFlip = false; int lastTech = -1;
+    int lastRestir = -1;                                              // technique of the last ReSTIR frame (-1: none since the buffers were zeroed): k_sync_history_normals
     uint32_t* externalImage = nullptr;
     // scene
     // what a device refit needs beyond the tree itself (fyprt_update_vertices): vertices, per-triangle vertex indices, the nodes of
@@ -225,7 +226,7 @@ int fyprt_resize(fyprt_context* c, uint32_t w, uint32_t h) {
     HIPCHK(c, sync_all(c));
     c->part1Pending = false;
     c->stripeRows = 0; c->stripeParts = 1; c->stripePart = 0;
-    c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->externalImage = nullptr;
+    c->W = w; c->H = h; c->frameIndex = 1; c->normalFlip = false; c->dprevFlip = false; c->lastTech = -1; c->lastRestir = -1; c->externalImage = nullptr;
     c->histDI[0] = c->histGI[0] = 0; c->histDI[1] = c->histGI[1] = h;        // zero-filled history: "valid" everywhere, M = 0
     if (!c->rowsSet || c->rowEnd > h) { c->rowBegin = 0; c->rowEnd = h; c->halo = 0; c->rowsSet = false; }
     return FYPRT_OK;
@@ -876,6 +877,10 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                 const size_t L1 = (size_t)steps1 + 2, L2 = (size_t)steps2 + 2;
                 { const int rc = ensure_paths(c, p1px, 1, 5, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
                 uint32_t* cnt1 = c->wfCounters.p; uint32_t* cnt2 = cnt1 + 2 * L1;      // cnt2[0] = length of the Part-2 list
+                if (phase != 2 && c->lastRestir == FYPRT_RESTIR_DI) {   // the last ReSTIR frame was a DI frame: its normals (in the history records) are this frame's "previous normals"
+                    const uint32_t npx = c->W * c->H;
+                    hipLaunchKernelGGL(k_sync_history_normals, dim3((npx + 255u) / 256u), dim3(256), 0, c->stream, const_cast<DIRec*>(fr.dprevRead), fr.normalPrev, npx, 0);
+                }
                 if (phase != 2) {
                     HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                     if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
@@ -890,6 +895,10 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                 launches = 2;
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;
                 break;
+            }
+            if (phase != 2 && c->lastRestir == FYPRT_RESTIR_GI) {   // the last ReSTIR frame was a GI frame: its normals are this frame's "previous normals"
+                const uint32_t npx = c->W * c->H;
+                hipLaunchKernelGGL(k_sync_history_normals, dim3((npx + 255u) / 256u), dim3(256), 0, fs, const_cast<DIRec*>(fr.dprevRead), fr.normalPrev, npx, 1);
             }
             if (phase != 2) {
                 if (c->countRays) hipLaunchKernelGGL(k_di_part1<true>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
@@ -950,6 +959,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
     HIPCHK(c, hipEventRecord(c->evDone[par], c->stream));                // the frame is complete (and its task queue free again)
     c->lastOverlapped = overlap;
     c->lastLaunches = launches; c->lastTech = tech;
+    if (tech == FYPRT_RESTIR_DI || tech == FYPRT_RESTIR_GI) c->lastRestir = tech;
     c->ringLaunches[c->frameSerial % fyprt_context::kRing] = timed ? launches : 0;
     c->ringSplit[c->frameSerial % fyprt_context::kRing] = overlap;
     c->frameSerial++;

@@ -159,6 +159,19 @@ __global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32
     nodeBox[(size_t)node * 2 + 1] = make_float4(nb.hi[0], nb.hi[1], nb.hi[2], 0.0f);
 }
 
+// The reference keeps ONE pair of octahedral-normal buffers for both ReSTIRs (R.cu: normalBuffers prev / cur, swapped after every ReSTIR
+// frame), so the "previous normal" a ReSTIR DI frame tests its history against is the last ReSTIR frame's — also when that was a GI
+// frame — and vice versa.  Here the DI history carries its normal inside the 32-byte record and GI has its own normal buffers; when
+// the technique changes between two ReSTIR frames this kernel carries the newest normals over, once (toRecords: GI buffer -> DI
+// history records; else DI history records -> GI buffer).
+__global__ void k_sync_history_normals(DIRec* records, f2* normals, uint32_t n, int toRecords) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4* q = reinterpret_cast<float4*>(records + i);
+    if (toRecords) { const f2 nn = normals[i]; float4 a = q[0]; a.y = nn.x; a.z = nn.y; q[0] = a; }
+    else { const float4 a = q[0]; f2 nn; nn.x = a.y; nn.y = a.z; normals[i] = nn; }
+}
+
 // fyprt_selftest_math: the three lean functions of rt_math.h against the compiler's correctly rounded sequences on every one of the
 // 2^32 binary32 arguments.  counts[which] = number of arguments with different result bits (NaN == NaN), first[which] = the smallest such.
 __global__ void k_math_selftest(int which, unsigned long long* counts, uint32_t* first) {

@@ -178,7 +178,9 @@ int fyprt_resize(fyprt_context* ctx, uint32_t width, uint32_t height);
 
 /* Multi-GPU tile split (new; BASELINE.json north_star): this context renders image rows
  * [row_begin,row_end) of the full width x height frame.  ReSTIR Part 1 is additionally run
- * on `halo_rows` rows either side (halo recompute).  Default: all rows. */
+ * on `halo_rows` rows either side (halo recompute).  Default: all rows.  With spatial reuse on, halo_rows must be
+ * at least spatial_neighbor_radius (or the rows must arrive by fyprt_group_* / fyprt_comm_* exchange): what a neighbour beyond
+ * band + halo holds is whatever an earlier frame left there. */
 int fyprt_set_rows(fyprt_context* ctx, uint32_t row_begin, uint32_t row_end, uint32_t halo_rows);
 /* The interleaved split of SURVEY.md §8(e) for the techniques whose pixels are independent (every technique but the two ReSTIRs:
  * PerPixel_* of Renderer.cu:565-1626 read nothing of another pixel): the frame is cut into stripes of `stripe_rows` rows and this
