@@ -23,7 +23,10 @@ NEUTRAL_KEYS = {0: [0, 1, 2], 1: [0, 1], 2: [0, 1, 3], 3: [0, 1], 4: [0, 16, 128
 
 def _random_settings(rng):
     tech = int(rng.integers(0, 9))
-    return capi.Settings(technique=tech, light_bounces=int(rng.integers(1, 4)), sample_count=int(rng.integers(1, 3)),
+    edge = rng.integers(0, 12) == 0                                       # now and then the values the kernels' uint8 casts and empty loops see
+    return capi.Settings(technique=tech, light_bounces=int(rng.choice([0, 257])) if edge else int(rng.integers(1, 4)),
+                         sample_count=int(rng.choice([0, 258])) if (edge and rng.integers(0, 2)) else int(rng.integers(1, 3)),
+                         to_accumulate=int(rng.integers(0, 8) != 0),
                          sky_color=tuple(float(x) for x in rng.uniform(0.0, 0.4, 3)), light_candidate_count=int(rng.integers(1, 9)),
                          use_temporal_reuse=int(rng.integers(0, 2)), use_spatial_reuse=int(rng.integers(0, 2)),
                          temporal_history_limit=int(rng.integers(1, 6)), spatial_neighbor_num=int(rng.integers(0, 6)),
