@@ -701,6 +701,19 @@ static shade_kernel_t shade_kernel(int stage) {
 // phase: 0 = the whole frame; 1 = ReSTIR Part 1 only (nothing of the frame's bookkeeping advances); 2 = the rest of the frame that a
 // phase-1 call started.  The split exists for the halo EXCHANGE of a multi-GPU frame (fyprt_multi.h): Part 1 on every band, the
 // bands' Part-1 records of each other's halo rows copied across, Part 2 on every band.
+// The "previous normals" of a ReSTIR frame are the last ReSTIR frame's, whichever of the two techniques rendered it (the reference keeps
+// one pair of normal buffers for both; rt_refit.h: k_sync_history_normals).  Called before Part 1 — by the multi-GPU layer before the
+// halo rows' history is fetched from their owners, so that what travels is already in step.
+static int sync_restir_normals(fyprt_context* c, int tech, hipStream_t stream) {
+    if (c->lastRestir < 0 || c->lastRestir == tech || c->W == 0) { return FYPRT_OK; }
+    const uint32_t npx = c->W * c->H;
+    DIRec* records = c->dprevFlip ? c->dprevB.p : c->dprevA.p;            // the history the next ReSTIR DI frame reads
+    f2* normals = c->normalFlip ? c->normalB.p : c->normalA.p;            // the previous normals the next ReSTIR GI frame reads
+    hipLaunchKernelGGL(k_sync_history_normals, dim3((npx + 255u) / 256u), dim3(256), 0, stream, records, normals, npx, tech == FYPRT_RESTIR_DI ? 1 : 0);
+    c->lastRestir = tech;
+    return c->hip(hipGetLastError(), "k_sync_history_normals");
+}
+
 static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool timed, int phase);
 static int enqueue_frame(fyprt_context* c, const fyprt_settings* s, bool timed, int phase = 0) {
     const int rc = enqueue_frame_impl(c, s, timed, phase);
@@ -877,10 +890,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                 const size_t L1 = (size_t)steps1 + 2, L2 = (size_t)steps2 + 2;
                 { const int rc = ensure_paths(c, p1px, 1, 5, 2 * L1 + 2 * L2); if (rc != FYPRT_OK) return rc; }
                 uint32_t* cnt1 = c->wfCounters.p; uint32_t* cnt2 = cnt1 + 2 * L1;      // cnt2[0] = length of the Part-2 list
-                if (phase != 2 && c->lastRestir == FYPRT_RESTIR_DI) {   // the last ReSTIR frame was a DI frame: its normals (in the history records) are this frame's "previous normals"
-                    const uint32_t npx = c->W * c->H;
-                    hipLaunchKernelGGL(k_sync_history_normals, dim3((npx + 255u) / 256u), dim3(256), 0, c->stream, const_cast<DIRec*>(fr.dprevRead), fr.normalPrev, npx, 0);
-                }
+                if (phase != 2) { const int rc = sync_restir_normals(c, tech, c->stream); if (rc != FYPRT_OK) return rc; }   // the last ReSTIR frame was a DI frame: its normals (in the history records) are this frame's "previous normals"
                 if (phase != 2) {
                     HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                     if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
@@ -896,10 +906,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                 c->normalFlip = !c->normalFlip; c->histGI[0] = c->rowBegin; c->histGI[1] = c->rowEnd;
                 break;
             }
-            if (phase != 2 && c->lastRestir == FYPRT_RESTIR_GI) {   // the last ReSTIR frame was a GI frame: its normals are this frame's "previous normals"
-                const uint32_t npx = c->W * c->H;
-                hipLaunchKernelGGL(k_sync_history_normals, dim3((npx + 255u) / 256u), dim3(256), 0, fs, const_cast<DIRec*>(fr.dprevRead), fr.normalPrev, npx, 1);
-            }
+            if (phase != 2) { const int rc = sync_restir_normals(c, tech, fs); if (rc != FYPRT_OK) return rc; }   // the last ReSTIR frame was a GI frame: its normals are this frame's "previous normals"
             if (phase != 2) {
                 if (c->countRays) hipLaunchKernelGGL(k_di_part1<true>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);
                 else hipLaunchKernelGGL(k_di_part1<false>, g1, block, ldsBytes, fs, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow);

@@ -10,6 +10,10 @@
 //                            and exchange for ReSTIR DI (1.8 MB per neighbour at 1080p), 96 B + 72 B for ReSTIR GI.  Every record is
 //                            then computed once, by its owner, with its full history: a static-camera sequence is bit-identical to the
 //                            single-GPU sequence on EVERY frame (tests/test_gpu_group.py), and Part 1 does 22 % less work at 8 bands.
+//                            The history rows fetched are the spatial halo but at least two (temporal reuse without spatial reuse
+//                            still reprojects onto the row above now and then), and a switch between the two ReSTIRs brings every
+//                            band's "previous normals" in step BEFORE they travel (tests/test_gpu_group_sequences.py: 400 random
+//                            sequences of techniques, settings, moved borders, restarts and interleave switches, all exact).
 // Two transports under the same plan (`halo_plan`):
 //   fyprt_group_*   one process, one context per GPU (what a C++ host such as the reference's application is): hipMemcpyPeerAsync
 //                   between the contexts' buffers, ordered with events — no collective library at all;
@@ -57,7 +61,10 @@ std::vector<XBuf> exchange_buffers(fyprt_context* c, int tech, int kind) {
         if (kind == 0) {
             v.push_back({c->gi.p, sizeof(GIRes)}); v.push_back({c->giHot.p, 4 * sizeof(float4)});        // Part 2 reads a neighbour's 64-byte record; the reservoir only of the finally selected sample
             v.push_back({c->normalFlip ? (void*)c->normalA.p : (void*)c->normalB.p, sizeof(f2)});      // this frame's normals: next frame's history normals
-        } else v.push_back({c->giPrev.p, sizeof(GIRes)});          // (last frame's normals of the halo rows arrived with last frame's Part-1 exchange)
+        } else {
+            v.push_back({c->giPrev.p, sizeof(GIRes)});
+            v.push_back({c->normalFlip ? (void*)c->normalB.p : (void*)c->normalA.p, sizeof(f2)});      // the previous normals the history is tested against
+        }
     }
     return v;
 }
@@ -66,7 +73,12 @@ bool is_restir(const fyprt_settings* s) { return s->technique == FYPRT_RESTIR_DI
 template <class F> void for_each_stripe(uint32_t H, uint32_t stripe, uint32_t parts, uint32_t part, F&& f) {
     for (uint64_t r0 = (uint64_t)part * stripe; r0 < H; r0 += (uint64_t)parts * stripe) f((uint32_t)r0, (uint32_t)std::min<uint64_t>(r0 + stripe, H));
 }
-bool wants_exchange(const fyprt_settings* s) { return (s->technique == FYPRT_RESTIR_DI || s->technique == FYPRT_RESTIR_GI) && s->use_spatial_reuse; }
+// rows around a band whose Part-1 records Part 2 reads (spatial reuse: the kernels' uint8 cast of the radius, R.cu:1897), and rows whose
+// temporal history Part 1 may be reprojected onto: the spatial halo, at least kHistoryRows (a static camera reprojects a pixel onto
+// itself or, by fp32 rounding of an exactly integral coordinate, onto its upper / left neighbour: Camera.cpp:143)
+constexpr uint32_t kHistoryRows = 2;
+uint32_t spatial_halo(const fyprt_settings* s, int n) { return (is_restir(s) && s->use_spatial_reuse && n > 1) ? ((uint32_t)s->spatial_neighbor_radius & 0xFFu) : 0u; }
+uint32_t history_halo(const fyprt_settings* s, int n) { return (is_restir(s) && s->use_temporal_reuse && n > 1) ? std::max(spatial_halo(s, n), kHistoryRows) : 0u; }
 void extend_history_rows(fyprt_context* c, int tech, uint32_t halo) {
     uint32_t* h = tech == FYPRT_RESTIR_DI ? c->histDI : c->histGI;
     h[0] = c->rowBegin > halo ? c->rowBegin - halo : 0u; h[1] = (c->rowEnd + halo < c->H) ? c->rowEnd + halo : c->H;
@@ -101,7 +113,7 @@ constexpr int kNcclChar = 0;      // ncclInt8 / ncclChar: transfers are counted 
 struct fyprt_group {
     std::vector<fyprt_context*> ctx; std::vector<uint32_t> bounds; int haloMode = 0;
     uint32_t stripeRows = 0; bool lastStriped = false;      // interleaved split for the per-pixel techniques; whether the last frame used it
-    std::vector<hipEvent_t> evP1, evPulled, evFrame; hipEvent_t evGather = nullptr; bool gatherPending = false; std::string err;
+    std::vector<hipEvent_t> evP1, evPulled, evFrame, evSync; hipEvent_t evGather = nullptr; bool gatherPending = false; std::string err;
 };
 
 int fyprt_group_synchronize(fyprt_group* g);
@@ -119,11 +131,11 @@ int fyprt_group_create(fyprt_context** ctxs, int n, const uint32_t* row_bounds, 
     if (row_bounds[0] != 0 || row_bounds[n] != ctxs[0]->H) return ctxs[0]->fail(FYPRT_EINVAL, "fyprt_group_create: the bands must partition rows 0..height");
     auto* g = new fyprt_group();
     g->ctx.assign(ctxs, ctxs + n); g->bounds.assign(row_bounds, row_bounds + n + 1);
-    g->evP1.resize(n); g->evPulled.resize(n); g->evFrame.resize(n);
+    g->evP1.resize(n); g->evPulled.resize(n); g->evFrame.resize(n); g->evSync.resize(n);
     for (int i = 0; i < n; ++i) {
         (void)hipSetDevice(ctxs[i]->device);
         (void)hipEventCreateWithFlags(&g->evP1[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&g->evPulled[i], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&g->evFrame[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&g->evFrame[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&g->evSync[i], hipEventDisableTiming);
     }
     (void)hipSetDevice(ctxs[0]->device);
     (void)hipEventCreateWithFlags(&g->evGather, hipEventDisableTiming);
@@ -134,7 +146,7 @@ void fyprt_group_destroy(fyprt_group* g) {
     if (!g) return;
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         (void)hipSetDevice(g->ctx[i]->device); (void)sync_all(g->ctx[i]);
-        (void)hipEventDestroy(g->evP1[i]); (void)hipEventDestroy(g->evPulled[i]); (void)hipEventDestroy(g->evFrame[i]);
+        (void)hipEventDestroy(g->evP1[i]); (void)hipEventDestroy(g->evPulled[i]); (void)hipEventDestroy(g->evFrame[i]); (void)hipEventDestroy(g->evSync[i]);
         g->ctx[i]->haloExchange = false;
     }
     if (g->evGather) (void)hipEventDestroy(g->evGather);
@@ -159,7 +171,8 @@ int fyprt_group_set_rows(fyprt_group* g, const uint32_t* row_bounds) {
             if (r0 >= r1) continue;                                   // rows [r0, r1): owned by j so far, by k from now on
             fyprt_context* o = g->ctx[j];
             auto move = [&](void* dst, const void* src, size_t bpp) { return hipMemcpyPeerAsync((char*)dst + (size_t)r0 * W * bpp, c->device, (const char*)src + (size_t)r0 * W * bpp, o->device, (size_t)(r1 - r0) * W * bpp, c->stream); };
-            HIPCHK(c, move(c->accum.p, o->accum.p, sizeof(float4)));
+            // (the accumulation of an interleaved frame lives in stripes, not in bands: nothing to move — every context keeps its stripes)
+            if (!g->lastStriped) HIPCHK(c, move(c->accum.p, o->accum.p, sizeof(float4)));
             HIPCHK(c, move(c->dprevFlip ? c->dprevB.p : c->dprevA.p, o->dprevFlip ? o->dprevB.p : o->dprevA.p, sizeof(DIRec)));
             HIPCHK(c, move(c->giPrev.p, o->giPrev.p, sizeof(GIRes)));
             HIPCHK(c, move(c->normalFlip ? c->normalB.p : c->normalA.p, o->normalFlip ? o->normalB.p : o->normalA.p, sizeof(f2)));
@@ -190,9 +203,8 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
     if (!g || !s) return FYPRT_EINVAL;
     const int n = (int)g->ctx.size();
     const uint32_t H = g->ctx[0]->H, W = g->ctx[0]->W;
-    const bool restir = wants_exchange(s);
-    const uint32_t halo = (restir && n > 1) ? ((uint32_t)s->spatial_neighbor_radius & 0xFFu) : 0u;      // the kernels' uint8 cast (R.cu:1897)
-    const bool exchange = g->haloMode == 1 && halo > 0;
+    const uint32_t halo = spatial_halo(s, n), hhalo = history_halo(s, n);
+    const bool exchange = g->haloMode == 1 && (halo > 0 || hhalo > 0);
     const bool striped = g->stripeRows != 0 && n > 1 && !is_restir(s);
     g->lastStriped = striped;
     for (int i = 0; i < n; ++i) {
@@ -213,7 +225,7 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
         }
         return FYPRT_OK;
     }
-    const std::vector<HaloXfer> plan = halo_plan(g->bounds, halo, H, true), hplan = halo_plan(g->bounds, halo, H, false);
+    const std::vector<HaloXfer> plan = halo_plan(g->bounds, halo, H, true), hplan = halo_plan(g->bounds, hhalo, H, false);
     auto pull = [&](int i, const std::vector<HaloXfer>& pl, int kind, const std::vector<hipEvent_t>& ready) -> int {
         fyprt_context* c = g->ctx[i];
         HIPCHK(c, hipSetDevice(c->device));
@@ -222,6 +234,7 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
             if (x.receiver != i) continue;
             fyprt_context* o = g->ctx[x.owner];
             HIPCHK(c, hipStreamWaitEvent(c->stream, ready[x.owner], 0));
+            if (kind == 1) HIPCHK(c, hipStreamWaitEvent(c->stream, g->evSync[x.owner], 0));      // the owner's history is in step with the technique
             const std::vector<XBuf> theirs = exchange_buffers(o, s->technique, kind);
             for (size_t b = 0; b < mine.size(); ++b) {
                 const size_t off = (size_t)x.r0 * W * mine[b].bytesPerPixel, bytes = (size_t)(x.r1 - x.r0) * W * mine[b].bytesPerPixel;
@@ -230,13 +243,20 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
         }
         return FYPRT_OK;
     };
+    // 0. a switch between the two ReSTIRs: every band brings its "previous normals" in step before anybody fetches them
+    for (int i = 0; i < n; ++i) {
+        fyprt_context* c = g->ctx[i];
+        HIPCHK(c, hipSetDevice(c->device));
+        { const int rc = sync_restir_normals(c, s->technique, c->stream); if (rc != FYPRT_OK) return rc; }
+        HIPCHK(c, hipEventRecord(g->evSync[i], c->stream));
+    }
     // 1. temporal history of the halo rows, then Part 1 on the band's own rows
     for (int i = 0; i < n; ++i) {
         fyprt_context* c = g->ctx[i];
         HIPCHK(c, hipSetDevice(c->device));
         for (int j = 0; j < n; ++j) if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, g->evPulled[j], 0));    // last frame's pulls FROM this band are done
         if (s->use_temporal_reuse) { const int rc = pull(i, hplan, 1, g->evFrame); if (rc != FYPRT_OK) return rc; }
-        extend_history_rows(c, s->technique, halo);
+        extend_history_rows(c, s->technique, hhalo);
         const int rc = enqueue_frame(c, s, true, 1);
         if (rc != FYPRT_OK) return rc;
         HIPCHK(c, hipEventRecord(g->evP1[i], c->stream));
@@ -361,6 +381,7 @@ int fyprt_comm_set_rows(fyprt_context* c, const uint32_t* row_bounds) {
             const uint32_t r0 = std::max(row_bounds[k], c->bounds[j]), r1 = std::min(row_bounds[k + 1], c->bounds[j + 1]);
             if (r0 >= r1 || (c->rank != k && c->rank != j)) continue;       // rows [r0, r1): owned by j so far, by k from now on
             for (const XBuf& b : bufs) {
+                if (b.p == (void*)c->accum.p && c->commLastStriped) continue;     // an interleaved frame's accumulation lives in stripes: nothing to move
                 const size_t off = (size_t)r0 * c->W * b.bytesPerPixel, bytes = (size_t)(r1 - r0) * c->W * b.bytesPerPixel;
                 if (c->rank == k) NCCLCHK(c, g_rccl.Recv((char*)b.p + off, bytes, kNcclChar, j, c->comm, c->stream));
                 else NCCLCHK(c, g_rccl.Send((const char*)b.p + off, bytes, kNcclChar, k, c->comm, c->stream));
@@ -398,17 +419,17 @@ static int comm_exchange(fyprt_context* c, int tech, const std::vector<HaloXfer>
 int fyprt_comm_render(fyprt_context* c, const fyprt_settings* s) {
     if (!c || !s) return FYPRT_EINVAL;
     if (!c->comm) return c->fail(FYPRT_ESTATE, "fyprt_comm_render before fyprt_comm_init_rank");
-    const bool restir = wants_exchange(s);
-    const uint32_t halo = (restir && c->world > 1) ? ((uint32_t)s->spatial_neighbor_radius & 0xFFu) : 0u;
-    const bool exchange = c->commHaloMode == 1 && halo > 0;
+    const uint32_t halo = spatial_halo(s, c->world), hhalo = history_halo(s, c->world);
+    const bool exchange = c->commHaloMode == 1 && (halo > 0 || hhalo > 0);
     c->rowBegin = c->bounds[c->rank]; c->rowEnd = c->bounds[c->rank + 1]; c->halo = halo; c->rowsSet = true; c->haloExchange = exchange;
     c->commLastStriped = c->commStripeRows != 0 && c->world > 1 && !is_restir(s);
     if (c->commLastStriped) { const int rc = fyprt_set_row_stripes(c, c->commStripeRows, (uint32_t)c->world, (uint32_t)c->rank); if (rc != FYPRT_OK) return rc; }
     else c->stripeRows = 0;
     if (!exchange) return enqueue_frame(c, s, true);
     HIPCHK(c, hipSetDevice(c->device));
-    if (s->use_temporal_reuse) { const int rc = comm_exchange(c, s->technique, halo_plan(c->bounds, halo, c->H, false), 1); if (rc != FYPRT_OK) return rc; }
-    extend_history_rows(c, s->technique, halo);
+    { const int rc = sync_restir_normals(c, s->technique, c->stream); if (rc != FYPRT_OK) return rc; }      // before the history travels
+    if (s->use_temporal_reuse) { const int rc = comm_exchange(c, s->technique, halo_plan(c->bounds, hhalo, c->H, false), 1); if (rc != FYPRT_OK) return rc; }
+    extend_history_rows(c, s->technique, hhalo);
     { const int rc = enqueue_frame(c, s, true, 1); if (rc != FYPRT_OK) return rc; }
     { const int rc = comm_exchange(c, s->technique, halo_plan(c->bounds, halo, c->H, true), 0); if (rc != FYPRT_OK) return rc; }
     return enqueue_frame(c, s, true, 2);

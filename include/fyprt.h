@@ -332,7 +332,9 @@ void fyprt_group_destroy(fyprt_group* group);                       /* the conte
 int fyprt_group_set_rows(fyprt_group* group, const uint32_t* row_bounds);
 int fyprt_group_set_halo_mode(fyprt_group* group, int mode);
 /* stripe_rows > 0: frames of the per-pixel techniques are split into interleaved stripes (fyprt_set_row_stripes, context i = part i),
- * ReSTIR frames keep the row bands; the gather moves stripes instead of bands.  Restart the accumulation when changing it. */
+ * ReSTIR frames keep the row bands; the gather moves stripes instead of bands.  The rows a context accumulates are the rows it
+ * renders: restart the accumulation (fyprt_reset_frame_index on every context) when changing this setting, and — while it is on —
+ * when switching between a ReSTIR and a per-pixel technique (the reference's host restarts it on any change of settings anyway). */
 int fyprt_group_set_interleave(fyprt_group* group, uint32_t stripe_rows);
 int fyprt_group_render(fyprt_group* group, const fyprt_settings* settings);   /* one frame on every band; asynchronous */
 int fyprt_group_gather(fyprt_group* group, int root);               /* all bands' RGBA8 rows into context `root`'s image; asynchronous */
