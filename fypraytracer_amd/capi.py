@@ -328,6 +328,10 @@ class Context:
     def render_async(self, settings: Settings):
         self._check(self.lib.fyprt_render_async(self.h, C.byref(settings)))
 
+    def render_part(self, settings: Settings, part: int):
+        """One of the two parts of a ReSTIR frame (asynchronous): what a host with its own transport for the halo rows calls."""
+        self._check(self.lib.fyprt_render_part(self.h, C.byref(settings), part))
+
     def synchronize(self):
         self._check(self.lib.fyprt_synchronize(self.h))
 

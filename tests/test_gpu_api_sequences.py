@@ -121,7 +121,11 @@ class Mirror:
     def frame(self, st, asynchronous):
         if self.stripes and st.technique >= capi.RESTIR_DI:
             self.set_stripes(None)                                           # ReSTIR frames need contiguous rows
-        if asynchronous:
+        if asynchronous and st.technique >= capi.RESTIR_DI and self.rng.integers(0, 2):
+            self.ctx.render_part(st, 1)                                      # the frame in two calls (a host that moves the halo rows itself)
+            self.ctx.render_part(st, 2)
+            self.ctx.synchronize()
+        elif asynchronous:
             self.ctx.render_async(st)
             self.ctx.synchronize()
         else:
