@@ -99,6 +99,10 @@ void orc_set_camera(orc_handle* h, const orc_camera_desc* c) {
     cam.width = c->viewport_width; cam.height = c->viewport_height;
     h->rr->cam = cam; h->rp->cam = cam;
 }
+// The per-pixel state (accumulation, image, reservoirs, history, normals, frame index) of `src` moves into `dst`: what the reference
+// does when the application replaces or edits the scene on a live renderer — SceneToGPU / FreeSceneGPU touch the scene only, every
+// per-pixel buffer stays (Renderer.cu:286-419 allocate them on a resize alone).  Both handles must have the same frame size.
+void orc_adopt_frame(orc_handle* dst, orc_handle* src) { dst->R().fr = std::move(src->R().fr); src->R().fr = Frame(); }
 void orc_reset_frame_index(orc_handle* h) { h->R().fr.frameIndex = 1; }
 uint32_t orc_frame_index(orc_handle* h) { return h->R().fr.frameIndex; }
 void orc_set_threads(int n) { omp_set_num_threads(n); }

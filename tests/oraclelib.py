@@ -35,6 +35,7 @@ def _load(name):
     lib.orc_set_product_bvh.argtypes = [vp, vp, u32, vp, u32, C.c_int32]
     lib.orc_set_camera.argtypes = [vp, C.POINTER(capi.CameraDesc)]
     lib.orc_reset_frame_index.argtypes = [vp]
+    lib.orc_adopt_frame.argtypes = [vp, vp]
     lib.orc_frame_index.argtypes = [vp]
     lib.orc_frame_index.restype = u32
     lib.orc_set_threads.argtypes = [C.c_int]
@@ -120,6 +121,11 @@ class Oracle:
 
     def use_reference_tracer(self):
         self.lib.orc_use_reference_tracer(self.h)
+
+    def adopt_frame(self, other):
+        """take over `other`'s per-pixel state (a scene replaced or edited on a live renderer keeps every per-pixel buffer)"""
+        assert (self.width, self.height) == (other.width, other.height)
+        self.lib.orc_adopt_frame(self.h, other.h)
 
     def reset_frame_index(self):
         self.lib.orc_reset_frame_index(self.h)

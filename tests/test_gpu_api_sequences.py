@@ -51,17 +51,16 @@ class Mirror:
         self.W, self.H = SIZES[0]
         self.ctx.resize(self.W, self.H)
         self.orc = None
-        self.rows, self.halo = None, 0
+        self.rows, self.halo, self.stripes = None, 0, None
         self.load("hall_small")
 
     def load(self, name):
         mk_scene, mk_cam = SCENES[name]
         self.name, self.sc, self.mk_cam = name, mk_scene(), mk_cam
         self.cam = mk_cam(self.W, self.H)
-        # The oracle has no "replace the scene" call: its twin starts over with empty per-pixel buffers, so the product does too (a
-        # resize zero-fills them; a band that still fits survives it).  What a replaced scene does to history that is NOT cleared is
-        # the subject of test_scene_replaced_with_fewer_lights... in tests/test_gpu_moving_camera.py.
-        self.ctx.resize(self.W, self.H)
+        # A scene replaced on a live renderer keeps every per-pixel buffer (the reference's SceneToGPU touches the scene only): the
+        # product's upload leaves them alone, the oracle's new twin adopts the old one's frame state.  History of another scene is
+        # then reused as far as it is valid (a DI history light index beyond the new emissive list reads as none).
         self.ctx.set_tuning(12, int(self.rng.integers(0, 3)))      # host SAH / device radix tree / device PLOC: the oracle walks whatever was built
         self.ctx.upload_scene(self.sc)
         self.ctx.set_camera(self.cam)
@@ -69,12 +68,11 @@ class Mirror:
         self.mgr = self.sc.manager()
         self.mgr.perform_all_scene_updates(self.sc)
         self.ctx.set_object_vertices(self.sc)
-        self.stripes = None
-        self._new_oracle()
+        self._new_oracle(adopt=True)
 
     def move_mesh(self):
-        """SceneManager transform edit -> device refit (by matrix or by re-uploaded vertices); the oracle starts over on the edited scene
-        walking the REFITTED tree, so the product's per-pixel buffers start over too."""
+        """SceneManager transform edit -> device refit (by matrix or by re-uploaded vertices); the oracle's twin of the edited scene walks
+        the REFITTED tree and adopts the frame state: reservoirs and history survive the edit on both sides (as in the reference)."""
         m = int(self.rng.integers(0, len(self.sc.meshes)))
         self.mgr.set_mesh_transform(self.sc, m, pos=tuple(float(x) for x in self.rng.uniform(-0.3, 0.3, 3)), rotation=(0.0, float(self.rng.uniform(-40, 40)), 0.0))
         self.mgr.perform_all_scene_updates(self.sc)
@@ -83,21 +81,19 @@ class Mirror:
             self.ctx.update_transforms(self.sc, [m])
         else:
             self.ctx.update_vertices(self.sc)
-        self.ctx.resize(self.W, self.H)
-        self.stripes = None
-        if self.rows:
-            self.ctx.set_rows(self.rows[0], self.rows[1], self.halo)
-        self.ctx.set_camera(self.cam)
         self.bvh = self.ctx.export_bvh()
-        self._new_oracle()
+        self._new_oracle(adopt=True)
         return m, by_matrix
 
-    def _new_oracle(self):
-        if self.orc is not None:
-            self.orc.close()
+    def _new_oracle(self, adopt=False):
+        old = self.orc
         self.orc = self.Oracle(self.sc, self.W, self.H)
         self.orc.set_camera(self.cam)
         self.orc.use_product_bvh(self.bvh)
+        if old is not None:
+            if adopt:
+                self.orc.adopt_frame(old)
+            old.close()
 
     def resize(self, W, H):
         self.W, self.H = W, H
