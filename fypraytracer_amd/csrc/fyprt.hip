@@ -58,7 +58,7 @@ struct fyprt_context {
     hipEvent_t ring[kRing][5] = {}; int ringLaunches[kRing] = {}; unsigned long long frameSerial = 0; hipEvent_t* ev = nullptr;
     uint32_t W = 0, H = 0, frameIndex = 1, rowBegin = 0, rowEnd = 0, halo = 0; bool rowsSet = false;
     uint32_t stripeRows = 0, stripeParts = 1, stripePart = 0;       // fyprt_set_row_stripes (per-pixel techniques only)
-    uint32_t commStripeRows = 0; bool commLastStriped = false;
+    uint32_t commStripeRows = 0, commLastStripeRows = 0; bool commLastStriped = false;
     int lastBuildRounds = 0;                                          // PLOC rounds of the last device build (diagnostic)
     bool haloExchange = false;   // halo rows of ReSTIR Part 1 come from the bands that own them (fyprt_multi.h) instead of being recomputed here
     bool part1Pending = false;   // fyprt_render_part(1) was called, part 2 must follow
@@ -291,8 +291,8 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
     float3 l3 = make_float3(lo[0], lo[1], lo[2]), ie = make_float3(hi[0] > lo[0] ? 1.0f / (hi[0] - lo[0]) : 0.0f, hi[1] > lo[1] ? 1.0f / (hi[1] - lo[1]) : 0.0f, hi[2] > lo[2] ? 1.0f / (hi[2] - lo[2]) : 0.0f);
     struct Temps {                      // scratch of the build, freed on every way out
         DevBuf<unsigned long long> keysA, keysB; DevBuf<uint32_t> valsA, valsB, parentOfNode, parentOfLeaf, arrived; DevBuf<float> box; DevBuf<RadixNode> radix; DevBuf<CollapseItem> qA, qB; DevBuf<uint32_t> counters; DevBuf<float4> wide; DevBuf<uint8_t> temp;
-        DevBuf<uint32_t> clA, clB, nearest; DevBuf<uint8_t> keep;                                   // PLOC
-        ~Temps() { clA.release(); clB.release(); nearest.release(); keep.release(); keysA.release(); keysB.release(); valsA.release(); valsB.release(); parentOfNode.release(); parentOfLeaf.release(); arrived.release(); box.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
+        DevBuf<uint32_t> clA, clB, nearest; DevBuf<uint8_t> keep, selTemp;                          // PLOC
+        ~Temps() { clA.release(); clB.release(); nearest.release(); keep.release(); selTemp.release(); keysA.release(); keysB.release(); valsA.release(); valsB.release(); parentOfNode.release(); parentOfLeaf.release(); arrived.release(); box.release(); radix.release(); qA.release(); qB.release(); counters.release(); wide.release(); temp.release(); }
     } t;
     auto &keysA = t.keysA, &keysB = t.keysB; auto &valsA = t.valsA, &valsB = t.valsB; auto& radix = t.radix;
     if (!ploc) {
@@ -322,7 +322,7 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
         HIPCHK(c, hipMemsetAsync(counters.p + 2, 0, 8, c->stream));                     // [2] binary nodes allocated, [3] clusters kept by the compaction
         size_t selBytes = 0;
         HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, selBytes, t.clB.p, t.keep.p, t.clA.p, counters.p + 3, (int)nT, c->stream));
-        DevBuf<uint8_t> selTemp; HIPCHK(c, selTemp.alloc(selBytes));
+        auto& selTemp = t.selTemp; HIPCHK(c, selTemp.alloc(selBytes));
         uint32_t n = nT; uint32_t* cur = t.clA.p; uint32_t* merged = t.clB.p; int force = 0, rounds = 0;
         while (n > 1) {
             const dim3 g((n + kPlocBlock - 1) / kPlocBlock);
@@ -332,13 +332,12 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
             uint32_t kept = 0;
             if (e == hipSuccess) e = hipMemcpyAsync(&kept, counters.p + 3, 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess || kept == 0 || kept >= n) { selTemp.release(); return e != hipSuccess ? c->hip(e, "PLOC round") : c->fail(FYPRT_EHIP, "PLOC round made no progress"); }
+            if (e != hipSuccess || kept == 0 || kept >= n) return e != hipSuccess ? c->hip(e, "PLOC round") : c->fail(FYPRT_EHIP, "PLOC round made no progress");
             if (env_int("FYPRT_BVH_DEBUG", 0)) std::fprintf(stderr, "PLOC round %d: %u -> %u clusters%s\n", rounds, n, kept, force ? " (forced)" : "");
             force = (!force && n > 4096u && kept > n - n / 16u) ? 1 : 0;
             n = kept; ++rounds;
         }
         HIPCHK(c, hipMemcpy(&rootNode, cur, 4, hipMemcpyDeviceToHost));
-        selTemp.release();
         c->lastBuildRounds = rounds;
     }
     HIPCHK(c, c->leafTris.alloc((size_t)nT * 3));
@@ -1038,7 +1037,8 @@ int fyprt_selftest_math(fyprt_context* c, uint64_t* mismatches3, uint32_t* first
     if (!c || !mismatches3) return FYPRT_EINVAL;
     if (c->hostOnly) return c->fail(FYPRT_ESTATE, "fyprt_selftest_math needs a device");
     HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
-    DevBuf<unsigned long long> counts; DevBuf<uint32_t> first;
+    struct Scratch { DevBuf<unsigned long long> counts; DevBuf<uint32_t> first; ~Scratch() { counts.release(); first.release(); } } scratch;
+    auto& counts = scratch.counts; auto& first = scratch.first;
     HIPCHK(c, counts.alloc(3)); HIPCHK(c, first.alloc(3));
     hipError_t e = hipMemsetAsync(counts.p, 0, 24, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(first.p, 0xFF, 12, c->stream);
@@ -1047,7 +1047,6 @@ int fyprt_selftest_math(fyprt_context* c, uint64_t* mismatches3, uint32_t* first
     if (e == hipSuccess) e = hipMemcpyAsync(hc, counts.p, 24, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hf, first.p, 12, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    counts.release(); first.release();
     HIPCHK(c, e);
     for (int w = 0; w < 3; ++w) { mismatches3[w] = hc[w]; if (first_bad3) first_bad3[w] = hf[w]; }
     return FYPRT_OK;

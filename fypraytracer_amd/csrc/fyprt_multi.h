@@ -112,7 +112,7 @@ constexpr int kNcclChar = 0;      // ncclInt8 / ncclChar: transfers are counted 
 
 struct fyprt_group {
     std::vector<fyprt_context*> ctx; std::vector<uint32_t> bounds; int haloMode = 0;
-    uint32_t stripeRows = 0; bool lastStriped = false;      // interleaved split for the per-pixel techniques; whether the last frame used it
+    uint32_t stripeRows = 0, lastStripeRows = 0; bool lastStriped = false;      // interleaved split for the per-pixel techniques; whether (and with which stripes) the last frame used it
     std::vector<hipEvent_t> evP1, evPulled, evFrame, evSync; hipEvent_t evGather = nullptr; bool gatherPending = false; std::string err;
 };
 
@@ -206,7 +206,7 @@ int fyprt_group_render(fyprt_group* g, const fyprt_settings* s) {
     const uint32_t halo = spatial_halo(s, n), hhalo = history_halo(s, n);
     const bool exchange = g->haloMode == 1 && (halo > 0 || hhalo > 0);
     const bool striped = g->stripeRows != 0 && n > 1 && !is_restir(s);
-    g->lastStriped = striped;
+    g->lastStriped = striped; g->lastStripeRows = g->stripeRows;
     for (int i = 0; i < n; ++i) {
         fyprt_context* c = g->ctx[i];
         c->rowBegin = g->bounds[i]; c->rowEnd = g->bounds[i + 1]; c->halo = halo; c->rowsSet = true; c->haloExchange = exchange;
@@ -292,7 +292,7 @@ int fyprt_group_gather(fyprt_group* g, int root) {
             const size_t off = (size_t)r0 * r->W, cnt = (size_t)(r1 - r0) * r->W;
             if (e == hipSuccess) e = hipMemcpyPeerAsync(dst + off, r->device, src + off, c->device, cnt * 4, r->stream);
         };
-        if (g->lastStriped) for_each_stripe(r->H, g->stripeRows, (uint32_t)g->ctx.size(), (uint32_t)i, rows);
+        if (g->lastStriped) for_each_stripe(r->H, g->lastStripeRows, (uint32_t)g->ctx.size(), (uint32_t)i, rows);
         else rows(g->bounds[i], g->bounds[i + 1]);
         HIPCHK(r, e);
     }
@@ -422,7 +422,7 @@ int fyprt_comm_render(fyprt_context* c, const fyprt_settings* s) {
     const uint32_t halo = spatial_halo(s, c->world), hhalo = history_halo(s, c->world);
     const bool exchange = c->commHaloMode == 1 && (halo > 0 || hhalo > 0);
     c->rowBegin = c->bounds[c->rank]; c->rowEnd = c->bounds[c->rank + 1]; c->halo = halo; c->rowsSet = true; c->haloExchange = exchange;
-    c->commLastStriped = c->commStripeRows != 0 && c->world > 1 && !is_restir(s);
+    c->commLastStriped = c->commStripeRows != 0 && c->world > 1 && !is_restir(s); c->commLastStripeRows = c->commStripeRows;
     if (c->commLastStriped) { const int rc = fyprt_set_row_stripes(c, c->commStripeRows, (uint32_t)c->world, (uint32_t)c->rank); if (rc != FYPRT_OK) return rc; }
     else c->stripeRows = 0;
     if (!exchange) return enqueue_frame(c, s, true);
@@ -457,7 +457,7 @@ int fyprt_comm_gather(fyprt_context* c, int root) {
             }
             if (e != 0 && bad == 0) bad = e;
         };
-        if (c->commLastStriped) for_each_stripe(c->H, c->commStripeRows, (uint32_t)c->world, (uint32_t)r, rows);      // one transfer per stripe, all in one group
+        if (c->commLastStriped) for_each_stripe(c->H, c->commLastStripeRows, (uint32_t)c->world, (uint32_t)r, rows);      // one transfer per stripe, all in one group
         else rows(c->bounds[r], c->bounds[r + 1]);
     }
     const int endRc = g_rccl.GroupEnd();
