@@ -126,7 +126,7 @@ EXPORTED_SYMBOLS = [
     "fyprt_set_ray_counting", "fyprt_set_tuning", "fyprt_version",
     "fyprt_group_create", "fyprt_group_destroy", "fyprt_group_set_rows", "fyprt_group_set_halo_mode", "fyprt_group_render", "fyprt_group_gather",
     "fyprt_group_synchronize", "fyprt_comm_unique_id", "fyprt_comm_init_rank", "fyprt_comm_set_rows", "fyprt_comm_set_halo_mode", "fyprt_comm_render",
-    "fyprt_comm_gather", "fyprt_comm_destroy", "fyprt_render_part", "fyprt_balance_rows", "fyprt_last_frame_ms", "fyprt_halo_plan",
+    "fyprt_comm_gather", "fyprt_comm_destroy", "fyprt_render_part", "fyprt_balance_rows", "fyprt_last_frame_ms", "fyprt_halo_plan", "fyprt_comm_ops",
     "fyprt_set_object_vertices", "fyprt_update_transforms", "fyprt_compare_image",
     "fyprt_set_row_stripes", "fyprt_group_set_interleave", "fyprt_comm_set_interleave", "fyprt_selftest_math",
 ]
@@ -205,10 +205,13 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.fyprt_balance_rows.argtypes = [C.POINTER(u32), C.POINTER(C.c_float), C.c_int, u32, u32, C.POINTER(u32)]
     lib.fyprt_last_frame_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fyprt_halo_plan.argtypes = [C.POINTER(u32), C.c_int, u32, u32, C.c_int, C.POINTER(u32), C.c_int]
+    if hasattr(lib, "fyprt_comm_ops"):       # (absent only in older builds loaded through FYPRT_LIB for an A/B run)
+        lib.fyprt_comm_ops.argtypes = [C.c_int, C.POINTER(u32), C.POINTER(u32), C.c_int, u32, u32, C.c_int, u32, C.c_int, C.POINTER(u32), C.c_int, C.POINTER(C.c_uint64), C.c_int]
+    alternative = path is not None or "FYPRT_LIB" in os.environ      # an older build loaded for an A/B run may lack the newest entry points
     for f in EXPORTED_SYMBOLS:
-        fn = getattr(lib, f)
-        if fn.restype is C.c_int:
-            pass
+        if alternative and not hasattr(lib, f):
+            continue
+        getattr(lib, f)                                                # the product library must export every symbol of include/fyprt.h
     if path is None:
         _lib = lib
     return lib
@@ -485,6 +488,21 @@ def balance_rows(row_bounds, band_ms, min_rows=16, max_shift=1 << 30, lib=None):
     if rc != 0:
         raise FyprtError(f"fyprt_balance_rows failed ({rc})")
     return list(out)
+
+
+def comm_ops(kind, row_bounds, rank, width, bytes_per_pixel, halo=0, height=0, wrap_row=True, new_bounds=None, lib=None):
+    """fyprt_comm_ops: [(is_recv, peer, buffer, offset, bytes), ...] that `rank` issues in one RCCL group section (kind 0: halo exchange,
+    kind 1: fyprt_comm_set_rows from row_bounds to new_bounds)."""
+    lib = lib or load_library()
+    n = len(row_bounds) - 1
+    nb = _u32_array(new_bounds) if new_bounds is not None else None
+    args = (kind, _u32_array(row_bounds), nb, n, halo, height, 1 if wrap_row else 0, width, rank, _u32_array(bytes_per_pixel), len(bytes_per_pixel))
+    cnt = lib.fyprt_comm_ops(*args, None, 0)
+    if cnt < 0:
+        raise FyprtError("fyprt_comm_ops: bad arguments")
+    out = (C.c_uint64 * (5 * max(cnt, 1)))()
+    lib.fyprt_comm_ops(*args, out, cnt)
+    return [tuple(int(v) for v in out[5 * k: 5 * k + 5]) for k in range(cnt)]
 
 
 def halo_plan(row_bounds, halo, height, wrap_row=True, lib=None):

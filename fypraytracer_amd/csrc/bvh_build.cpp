@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <queue>
 #include "rt_host.h"
 
 namespace rth {
@@ -140,7 +141,7 @@ struct Builder {
 // single "resume this node" entry (rt_device.h: node_step), so the pending-entry count can never exceed
 // kStackBudget as long as the tree has at most kStackBudget levels — which BuildSceneBVH guarantees.
 struct Collapser {
-    const std::vector<Node2>& bn; std::vector<uint8_t> height; std::vector<Node> out;
+    const std::vector<Node2>& bn; std::vector<uint8_t> height; std::vector<Node> out; std::vector<float> outArea;   // outArea: surface area of each wide node's box (visit probability of a random ray)
     // SAH-optimal collapse (dynamic programme over the binary tree): cost[n][j-1] = least sum of wide-node surface areas that
     // covers the subtree of binary node n with at most j roots (a root is a wide node or a leaf reference); sel[n][j-1] = how
     // the j roots are dealt to the two children ({0,0} = "n itself is the one root").  The expected number of node visits of a
@@ -216,11 +217,12 @@ struct Collapser {
         for (int j0 = 1; j0 < 4; ++j0) { const float v = T(bnode.child0, j0) + T(bnode.child1, 4 - j0); if (v < best) { best = v; bj0 = j0; } }
         roots(bnode.child0, b0, bj0, ch, k); roots(bnode.child1, b1, 4 - bj0, ch, k);
         const int32_t self = (int32_t)out.size();
-        out.emplace_back();
+        out.emplace_back(); outArea.push_back(0.0f);
+        if (self == 0) { Box nb; for (int i = 0; i < k; ++i) nb.grow(ch[i].b); outArea[0] = nb.area(); }
         Node n; quantise(n, ch, k);
         uint32_t below = 0;
         for (int i = 0; i < k; ++i) {
-            if (ch[i].ref >= 0) { uint32_t cl = 0; n.child[i] = emit(ch[i].ref, cl); below = std::max(below, cl); }
+            if (ch[i].ref >= 0) { uint32_t cl = 0; n.child[i] = emit(ch[i].ref, cl); outArea[(size_t)n.child[i]] = ch[i].b.area(); below = std::max(below, cl); }
             else n.child[i] = ch[i].ref;
         }
         for (int i = k; i < 4; ++i) n.child[i] = INT32_MIN;                       // never read: the count masks the slot
@@ -350,6 +352,27 @@ static void BuildWithDepthBound(const fyprt_vertex* verts, const uint8_t* tris, 
     if (std::getenv("FYPRT_BVH_DEBUG")) std::fprintf(stderr, "[bvh] collapse objective (sum of wide-node areas ~ expected node visits): width 2 %.4g, 4 %.4g, 6 %.4g, 8 %.4g\n",
                                                      collapseObjective<2>(bin, binRoot), collapseObjective<4>(bin, binRoot), collapseObjective<6>(bin, binRoot), collapseObjective<8>(bin, binRoot));
     out.nodes.swap(col.out);
+    // Node order = decreasing box area (a priority-queue sweep from the root): the nodes a ray is most likely to visit form a prefix of
+    // the array — the kernels keep that prefix in LDS (DevScene::topCount) — and hot nodes share cache lines further down.
+    if (!std::getenv("FYPRT_BVH_PREORDER") && out.rootRef >= 0) {
+        const size_t n = out.nodes.size();
+        std::vector<int32_t> newIndex(n, -1); std::vector<int32_t> order; order.reserve(n);
+        std::priority_queue<std::pair<float, int32_t>> pq;            // ties: the larger old index first (deterministic either way)
+        pq.push({col.outArea[(size_t)out.rootRef], out.rootRef});
+        while (!pq.empty()) {
+            const int32_t old = pq.top().second; pq.pop();
+            newIndex[(size_t)old] = (int32_t)order.size(); order.push_back(old);
+            const Node& nd = out.nodes[(size_t)old];
+            for (uint32_t i = 0; i < (nd.meta & 7u); ++i) if (nd.child[i] >= 0) pq.push({col.outArea[(size_t)nd.child[i]], nd.child[i]});
+        }
+        std::vector<Node> re(n);
+        for (size_t k = 0; k < n; ++k) {
+            Node nd = out.nodes[(size_t)order[k]];
+            for (uint32_t i = 0; i < (nd.meta & 7u); ++i) if (nd.child[i] >= 0) nd.child[i] = newIndex[(size_t)nd.child[i]];
+            re[k] = nd;
+        }
+        out.nodes.swap(re); out.rootRef = newIndex[(size_t)out.rootRef];
+    }
 }
 
 void BuildSceneBVH(const fyprt_vertex* verts, const uint8_t* tris, uint32_t triStride, const fyprt_mesh* meshes,

@@ -62,6 +62,7 @@ struct fyprt_context {
     int lastBuildRounds = 0;                                          // PLOC rounds of the last device build (diagnostic)
     bool haloExchange = false;   // halo rows of ReSTIR Part 1 come from the bands that own them (fyprt_multi.h) instead of being recomputed here
     bool part1Pending = false;   // fyprt_render_part(1) was called, part 2 must follow
+    bool blockingCall = false;   // inside fyprt_render (which synchronises anyway): long path stages may poll the live-path count from the host
     uint32_t histDI[2] = {0, 0}, histGI[2] = {0, 0};   // rows [begin, end) whose ReSTIR DI / GI history this context holds (the band of the last such frame)
     bool haveScene = false, haveCamera = false, countRays = false;
     // per-pixel buffers
@@ -89,7 +90,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[16] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, 0, 0, 0, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
@@ -161,6 +162,7 @@ int fyprt_create(int device_ordinal, fyprt_context** out) {
     if (e != hipSuccess) { g_createError = std::string("front stream / events: ") + hipGetErrorString(e); delete c; return FYPRT_EHIP; }
     for (auto& row : c->ring) for (auto& e : row) (void)hipEventCreate(&e);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
+    if (const char* e = std::getenv("FYPRT_TOP_NODES")) c->tuning[16] = std::min(1024, std::max(0, std::atoi(e)));
     (void)c->queueCounters.alloc(8);          // two queues (frame parity): tail, head, pad, pad each
     (void)c->rayCounter.alloc(32);            // 4 launches x (rays, box tests, triangle tests, hits, node visits, 3 unused)
     (void)hipMemset(c->rayCounter.p, 0, 256);
@@ -757,7 +759,8 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
     // and more workgroups fit a CU (LDS is what limits residency: (budget + 1) KB per 256-thread workgroup)
     const int budget = effective_stack_budget(c);
     c->dsc.stackBudget = budget;
-    const size_t ldsBytes = (size_t)(budget + 1) * kBlock * sizeof(int32_t);
+    c->dsc.topCount = (uint32_t)std::min<size_t>((size_t)std::max(0, c->tuning[16]), c->hostBvh.nodes.size());
+    const size_t ldsBytes = (size_t)(budget + 1) * kBlock * sizeof(int32_t) + (size_t)c->dsc.topCount * 64u;
     // Pipelining (tuning key 11): a wavefront ReSTIR DI frame runs Part 1 + setup on the front stream and the trace kernel on
     // `stream`.  Nothing the front part writes is read or written by a trace kernel (payload, records, history, depth, its own
     // task queue — two queues alternate), and image + accumulation are touched by trace kernels only (p1Mode 1), which stay in
@@ -807,6 +810,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
         tsc.rayCounter = c->countRays ? c->rayCounter.p + 8 * r.counterPart : nullptr;
         for (uint32_t it = 0; it <= r.steps; ++it) {
             PathIO io{};
+            io.fusedOwner = kNotFused;
             io.pixelList = r.pixelList; io.raysIn = c->wfRays[it & 1u].p; io.hitsIn = c->wfHits[it & 1u].p; io.countIn = r.cnt + it;
             io.raysOut = c->wfRays[(it + 1u) & 1u].p; io.countOut = r.cnt + it + 1; io.state = c->wfState.p; io.stateStride = r.stride;
             io.iteration = it; io.raysPer = r.raysPer; io.part2List = r.part2List; io.part2Count = r.part2Count;
@@ -835,7 +839,10 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
             }
             else if (c->countRays) hipLaunchKernelGGL(k_trace_rays<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
             else hipLaunchKernelGGL(k_trace_rays<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, q);
-            if (r.steps > 8u && (it & 3u) == 3u) {                   // long sample x bounce products: stop once no path is alive any more
+            // long sample x bounce products: stop once no path is alive any more.  Only inside the blocking fyprt_render — an asynchronous
+            // call (fyprt_render_async, group / comm frames) must not wait on the device: there the remaining steps are launched and find
+            // empty lists (every kernel of a step returns at once on a count of zero)
+            if (c->blockingCall && r.steps > 8u && (it & 3u) == 3u) {
                 uint32_t alive = 0;
                 HIPCHK(c, hipMemcpyAsync(&alive, io.countOut, 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -862,6 +869,18 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
             { const int rc = ensure_paths(c, entries, raysPer, stride, 3 * L); if (rc != FYPRT_OK) return rc; }
             HIPCHK(c, hipMemsetAsync(c->wfCounters.p, 0, 3 * L * sizeof(uint32_t), c->stream));
             c->dsc.nodeQuorum = (uint32_t)c->tuning[7];             // coherent primary rays
+            // small trees, techniques 0-5: the whole frame in one launch, one thread per pixel (rt_paths.h: k_path_fused; key 17: 0 = by tree size, 1 = never, 2 = always)
+            const bool fused = tech != FYPRT_NEE && (c->tuning[17] == 2 || (c->tuning[17] == 0 && c->hostBvh.tris.size() < 65536u));
+            if (fused) {
+                PathIO io{};
+                io.fusedOwner = kNotFused; io.raysIn = c->wfRays[0].p; io.raysOut = c->wfRays[0].p; io.hitsIn = c->wfHits[0].p; io.state = c->wfState.p; io.stateStride = stride; io.raysPer = 1u;
+                typedef void (*fused_kernel_t)(DevScene, DevCamera, DevFrame, DevSettings, PathIO, uint32_t);
+                static const fused_kernel_t kFused[2][6] = {{k_path_fused<T_BRUTE, false>, k_path_fused<T_UNIFORM, false>, k_path_fused<T_COSINE, false>, k_path_fused<T_GGX, false>, k_path_fused<T_BRDF, false>, k_path_fused<T_LIGHT, false>},
+                                                            {k_path_fused<T_BRUTE, true>, k_path_fused<T_UNIFORM, true>, k_path_fused<T_COSINE, true>, k_path_fused<T_GGX, true>, k_path_fused<T_BRDF, true>, k_path_fused<T_LIGHT, true>}};
+                hipLaunchKernelGGL(kFused[c->countRays ? 1 : 0][tech], pgrid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, io, steps);
+                launches = 1;
+                break;
+            }
             if (c->countRays) hipLaunchKernelGGL(k_primary<true>, pgrid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
             else hipLaunchKernelGGL(k_primary<false>, pgrid, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, c->wfPixels.p, c->wfCounters.p);
             StageRun r{tech, steps, raysPer, stride, c->wfPixels.p, c->wfCounters.p, c->wfCounters.p + L, (tech == FYPRT_NEE) ? c->wfPixels2.p : nullptr, nullptr, 0, (tech == FYPRT_NEE) ? c->wfCounters.p + 2 * L : nullptr, entries};
@@ -975,7 +994,9 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
 
 int fyprt_render(fyprt_context* c, const fyprt_settings* s, fyprt_frame_stats* stats) {
     if (!c || !s) return FYPRT_EINVAL;
+    c->blockingCall = true;
     int rc = enqueue_frame(c, s, true);
+    c->blockingCall = false;
     if (rc != FYPRT_OK) return rc;
     HIPCHK(c, sync_all(c));                            // cudaDeviceSynchronize, Renderer.cu:237
     if (stats) {
@@ -1165,17 +1186,17 @@ int fyprt_export_lighttrees(fyprt_context* c, fyprt_lighttree_node* tlas, uint32
 }
 
 int fyprt_get_tuning(fyprt_context* c, int key, int* value) {
-    if (!c || !value || key < 0 || key >= 16) return FYPRT_EINVAL;
+    if (!c || !value || key < 0 || key >= 24) return FYPRT_EINVAL;
     *value = (key == 8) ? effective_stack_budget(c) : (key == 2 && c->tuning[2] <= 0) ? c->traceOcc : c->tuning[key];   // key 2: residency found at the last DI frame
     return FYPRT_OK;
 }
 
 int fyprt_set_tuning(fyprt_context* c, int key, int value) {
-    if (!c || key < 0 || key >= 16) return FYPRT_EINVAL;
+    if (!c || key < 0 || key >= 24) return FYPRT_EINVAL;
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
-    static const int lo[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[16] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2};
+    static const int lo[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int hi[24] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2, 1024, 2, 0, 0, 0, 0, 0, 0};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

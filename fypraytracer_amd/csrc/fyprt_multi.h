@@ -107,6 +107,38 @@ struct Rccl {
 } g_rccl;
 constexpr int kNcclChar = 0;      // ncclInt8 / ncclChar: transfers are counted in bytes
 
+// The point-to-point operations ONE rank issues inside one ncclGroupStart / ncclGroupEnd section, in issue order.  RCCL matches the
+// sends and receives of a pair of ranks in the order each side issues them, so what has to hold — and what tests/test_multigpu_plan.py
+// checks on the CPU for every pair, since more than one rank per device cannot run on the one-GPU box — is that rank a's sends to b
+// and rank b's receives from a list the same byte counts in the same order.  Both functions are pure: (plan, rank) -> list.
+struct CommOp { int recv, peer, buf; size_t offset, bytes; };
+std::vector<CommOp> comm_exchange_ops(int rank, const std::vector<HaloXfer>& plan, const std::vector<size_t>& bytesPerPixel, uint32_t W) {
+    std::vector<CommOp> ops;
+    for (const HaloXfer& x : plan)
+        for (size_t b = 0; b < bytesPerPixel.size(); ++b) {
+            const size_t off = (size_t)x.r0 * W * bytesPerPixel[b], bytes = (size_t)(x.r1 - x.r0) * W * bytesPerPixel[b];
+            if (x.receiver == rank) ops.push_back({1, x.owner, (int)b, off, bytes});
+            else if (x.owner == rank) ops.push_back({0, x.receiver, (int)b, off, bytes});
+        }
+    return ops;
+}
+// rows that change owner when the band table `oldB` is replaced by `newB`: [r0, r1) owned by j so far, by k from now on
+std::vector<CommOp> comm_set_rows_ops(int rank, const std::vector<uint32_t>& oldB, const std::vector<uint32_t>& newB, const std::vector<size_t>& bytesPerPixel, uint32_t W) {
+    std::vector<CommOp> ops;
+    const int n = (int)oldB.size() - 1;
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j) {
+            if (j == k) continue;
+            const uint32_t r0 = std::max(newB[k], oldB[j]), r1 = std::min(newB[k + 1], oldB[j + 1]);
+            if (r0 >= r1 || (rank != k && rank != j)) continue;
+            for (size_t b = 0; b < bytesPerPixel.size(); ++b) {
+                const size_t off = (size_t)r0 * W * bytesPerPixel[b], bytes = (size_t)(r1 - r0) * W * bytesPerPixel[b];
+                ops.push_back({rank == k ? 1 : 0, rank == k ? j : k, (int)b, off, bytes});
+            }
+        }
+    return ops;
+}
+
 }  // namespace
 }  // extern "C++"
 
@@ -118,6 +150,21 @@ struct fyprt_group {
 
 int fyprt_group_synchronize(fyprt_group* g);
 #define NCCLCHK(c, call) do { const int _r = (call); if (_r != 0) return (c)->fail(FYPRT_EHIP, std::string(#call) + ": " + g_rccl.GetErrorString(_r)); } while (0)
+// One group section: every operation of `ops` on the context's stream.  An error inside the section still closes it (an open group
+// would swallow every later fyprt_comm_* call of this thread and the next synchronize would wait for ever).
+static int comm_issue(fyprt_context* c, const std::vector<CommOp>& ops, const std::vector<void*>& base) {
+    NCCLCHK(c, g_rccl.GroupStart());
+    int bad = 0;
+    for (const CommOp& o : ops) {
+        char* p = (char*)base[(size_t)o.buf] + o.offset;
+        const int e = o.recv ? g_rccl.Recv(p, o.bytes, kNcclChar, o.peer, c->comm, c->stream) : g_rccl.Send(p, o.bytes, kNcclChar, o.peer, c->comm, c->stream);
+        if (e != 0) { bad = e; break; }
+    }
+    const int endRc = g_rccl.GroupEnd();
+    if (bad != 0) return c->fail(FYPRT_EHIP, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(bad));
+    NCCLCHK(c, endRc);
+    return FYPRT_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ one process, one context per GPU
 int fyprt_group_create(fyprt_context** ctxs, int n, const uint32_t* row_bounds, fyprt_group** out) {
@@ -372,22 +419,17 @@ int fyprt_comm_set_rows(fyprt_context* c, const uint32_t* row_bounds) {
     if (row_bounds[0] != 0 || row_bounds[c->world] != c->H) return c->fail(FYPRT_EINVAL, "fyprt_comm_set_rows: the bands must partition rows 0..height");
     for (int i = 0; i < c->world; ++i) if (row_bounds[i] >= row_bounds[i + 1]) return c->fail(FYPRT_EINVAL, "fyprt_comm_set_rows: empty or unordered band");
     HIPCHK(c, hipSetDevice(c->device));
-    XBuf bufs[4] = {{c->accum.p, sizeof(float4)}, {c->dprevFlip ? (void*)c->dprevB.p : (void*)c->dprevA.p, sizeof(DIRec)}, {c->giPrev.p, sizeof(GIRes)},
-                    {c->normalFlip ? (void*)c->normalB.p : (void*)c->normalA.p, sizeof(f2)}};
-    NCCLCHK(c, g_rccl.GroupStart());
-    for (int k = 0; k < c->world; ++k)
-        for (int j = 0; j < c->world; ++j) {
-            if (j == k) continue;
-            const uint32_t r0 = std::max(row_bounds[k], c->bounds[j]), r1 = std::min(row_bounds[k + 1], c->bounds[j + 1]);
-            if (r0 >= r1 || (c->rank != k && c->rank != j)) continue;       // rows [r0, r1): owned by j so far, by k from now on
-            for (const XBuf& b : bufs) {
-                if (b.p == (void*)c->accum.p && c->commLastStriped) continue;     // an interleaved frame's accumulation lives in stripes: nothing to move
-                const size_t off = (size_t)r0 * c->W * b.bytesPerPixel, bytes = (size_t)(r1 - r0) * c->W * b.bytesPerPixel;
-                if (c->rank == k) NCCLCHK(c, g_rccl.Recv((char*)b.p + off, bytes, kNcclChar, j, c->comm, c->stream));
-                else NCCLCHK(c, g_rccl.Send((const char*)b.p + off, bytes, kNcclChar, k, c->comm, c->stream));
-            }
-        }
-    NCCLCHK(c, g_rccl.GroupEnd());
+    // Between two frames for real: a pipelined ReSTIR DI frame still has Part 1 + setup of the NEXT frame in flight on the front stream,
+    // and they read and write the very history rows that move here.  Everything of this context drains first, and the call returns only
+    // once the rows have arrived — exactly what fyprt_group_set_rows does around its peer copies.
+    HIPCHK(c, sync_all(c));
+    std::vector<void*> base; std::vector<size_t> bpp;
+    if (!c->commLastStriped) { base.push_back(c->accum.p); bpp.push_back(sizeof(float4)); }     // an interleaved frame's accumulation lives in stripes: nothing to move
+    base.push_back(c->dprevFlip ? (void*)c->dprevB.p : (void*)c->dprevA.p); bpp.push_back(sizeof(DIRec));
+    base.push_back(c->giPrev.p); bpp.push_back(sizeof(GIRes));
+    base.push_back(c->normalFlip ? (void*)c->normalB.p : (void*)c->normalA.p); bpp.push_back(sizeof(f2));
+    { const int rc = comm_issue(c, comm_set_rows_ops(c->rank, c->bounds, std::vector<uint32_t>(row_bounds, row_bounds + c->world + 1), bpp, c->W), base); if (rc != FYPRT_OK) return rc; }
+    HIPCHK(c, sync_all(c));
     c->bounds.assign(row_bounds, row_bounds + c->world + 1);
     c->rowBegin = c->bounds[c->rank]; c->rowEnd = c->bounds[c->rank + 1];
     c->histDI[0] = c->histGI[0] = c->rowBegin; c->histDI[1] = c->histGI[1] = c->rowEnd;
@@ -405,15 +447,9 @@ void fyprt_comm_destroy(fyprt_context* c) { if (c && c->comm && g_rccl.lib) { (v
 
 static int comm_exchange(fyprt_context* c, int tech, const std::vector<HaloXfer>& plan, int kind) {
     const std::vector<XBuf> bufs = exchange_buffers(c, tech, kind);
-    NCCLCHK(c, g_rccl.GroupStart());
-    for (const HaloXfer& x : plan)
-        for (const XBuf& b : bufs) {
-            const size_t off = (size_t)x.r0 * c->W * b.bytesPerPixel, bytes = (size_t)(x.r1 - x.r0) * c->W * b.bytesPerPixel;
-            if (x.receiver == c->rank) NCCLCHK(c, g_rccl.Recv((char*)b.p + off, bytes, kNcclChar, x.owner, c->comm, c->stream));
-            else if (x.owner == c->rank) NCCLCHK(c, g_rccl.Send((const char*)b.p + off, bytes, kNcclChar, x.receiver, c->comm, c->stream));
-        }
-    NCCLCHK(c, g_rccl.GroupEnd());
-    return FYPRT_OK;
+    std::vector<void*> base; std::vector<size_t> bpp;
+    for (const XBuf& b : bufs) { base.push_back(b.p); bpp.push_back(b.bytesPerPixel); }
+    return comm_issue(c, comm_exchange_ops(c->rank, plan, bpp, c->W), base);
 }
 // One frame of this rank's band (asynchronous).  Every rank of the communicator must call it with the same settings.
 int fyprt_comm_render(fyprt_context* c, const fyprt_settings* s) {
@@ -474,4 +510,20 @@ int fyprt_halo_plan(const uint32_t* row_bounds, int n, uint32_t halo, uint32_t h
         out4[4 * k] = (uint32_t)plan[k].receiver; out4[4 * k + 1] = (uint32_t)plan[k].owner; out4[4 * k + 2] = plan[k].r0; out4[4 * k + 3] = plan[k].r1;
     }
     return (int)plan.size();
+}
+
+// Test hook: the point-to-point operations rank `rank` issues in one group section — kind 0: a halo exchange over `bounds` (halo rows,
+// wrap row as fyprt_halo_plan); kind 1: fyprt_comm_set_rows from `bounds` to `new_bounds`.  out5 = (is_recv, peer, buffer, offset, bytes)
+// per operation; returns the number of operations.  Pure host arithmetic: no device, no RCCL.
+int fyprt_comm_ops(int kind, const uint32_t* bounds, const uint32_t* new_bounds, int n, uint32_t halo, uint32_t height, int wrap_row, uint32_t width,
+                   int rank, const uint32_t* bytes_per_pixel, int nbuf, uint64_t* out5, int capacity) {
+    if (!bounds || n <= 0 || rank < 0 || rank >= n || !bytes_per_pixel || nbuf <= 0 || (kind == 1 && !new_bounds)) return -1;
+    const std::vector<uint32_t> b(bounds, bounds + n + 1);
+    const std::vector<size_t> bpp(bytes_per_pixel, bytes_per_pixel + nbuf);
+    const std::vector<CommOp> ops = kind == 0 ? comm_exchange_ops(rank, halo_plan(b, halo, height, wrap_row != 0), bpp, width)
+                                               : comm_set_rows_ops(rank, b, std::vector<uint32_t>(new_bounds, new_bounds + n + 1), bpp, width);
+    for (int k = 0; k < (int)ops.size() && k < capacity && out5; ++k) {
+        out5[5 * k] = (uint64_t)ops[k].recv; out5[5 * k + 1] = (uint64_t)ops[k].peer; out5[5 * k + 2] = (uint64_t)ops[k].buf; out5[5 * k + 3] = ops[k].offset; out5[5 * k + 4] = ops[k].bytes;
+    }
+    return (int)ops.size();
 }

@@ -27,6 +27,7 @@ struct DevScene {
     const DevLTNode* ltTlas; uint32_t ltTlasCount, ltTlasRoot;
     const DevLTNode* ltBlas; const uint32_t* ltFirst; const uint32_t* ltCount; const uint32_t* ltRoot; const uint32_t* ltLeafOfTri;
     unsigned long long* rayCounter;   // instrumented kernel variants (template COUNT) only: [0] rays [1] box tests [2] triangle tests [3] hits [4] node visits
+    uint32_t topCount;                // nodes [0, topCount) are also kept in LDS by the traversal kernels (Stack::top4)
     int32_t stackBudget;              // pending-entry budget of node_step's stack rule (kStackBudget; tests lower it to exercise resume entries)
     uint32_t nodeQuorum;              // leave the inner-node loop when fewer lanes than this are still in it (0 = never)
 };
@@ -102,9 +103,21 @@ constexpr int32_t kExit = (int32_t)0x80000000;
 struct Stack {
     int32_t* lds;                 // &shared[threadIdx.x]
     int top;
+    // LDS copy of the first `topCount` nodes of the array (the builder orders nodes by decreasing box area, so these are the nodes a
+    // ray is most likely to visit: 128 of the bench tree's 194 k nodes take a third of all visits): a visit of one of them costs three
+    // ds_read_b128 instead of four vector-L1 look-ups per lane — the look-up rate of the vector L1 is what bounds the trace kernels
+    const float4* top4 = nullptr; uint32_t topCount = 0;
     RT_DEV void push(int32_t v) { lds[top * kBlock] = v; ++top; }
     RT_DEV int32_t pop() { --top; return lds[top * kBlock]; }
 };
+
+// workgroup prologue of a traversal kernel: the LDS copy of the hottest nodes behind the (budget + 1) x kBlock stack entries
+RT_DEV const float4* stage_top_nodes(const float4* nodes, uint32_t topCount, int32_t budget, int32_t* s_stack) {
+    float4* dst = reinterpret_cast<float4*>(s_stack + (size_t)(budget + 1) * kBlock);
+    for (uint32_t k = threadIdx.x; k < topCount * 4u; k += (uint32_t)kBlock) dst[k] = nodes[k];
+    __syncthreads();
+    return dst;
+}
 
 // One visit of a 4-wide node (layout: rt_host.h).  The child planes are never materialised: with the grid step s_a = 2^(e_a-127)
 // and the node origin g, the slab parameter of plane "g_a + q * s_a" is  t = q * (s_a / d_a) + (g_a - o_a) / d_a = fma(q, A_a, B_a),
@@ -118,17 +131,20 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct RayPk { float ox, oy, oz, ix, iy, iz; };
 RT_DEV RayPk make_raypk(f3 o, float ix, float iy, float iz) { RayPk r; r.ox = o.x; r.oy = o.y; r.oz = o.z; r.ix = ix; r.iy = iy; r.iz = iz; return r; }
 RT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); }
+// (the entry parameter is clamped to a tiny positive number instead of zero: as the high word of a sort key it must be a normal number, see node_step)
+constexpr float kNearClamp = 1e-30f;
 // entry / exit parameter of two children (x = first, y = second of the pair) from their near / far plane parameters
 RT_DEV void slab_of_pair(v2f nx, v2f fx, v2f ny, v2f fy, v2f nz, v2f fz, float cut, float& n0, float& f0, float& n1, float& f1) {
-    n0 = __builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), __builtin_fmaxf(nz.x, 0.0f));
+    n0 = __builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), __builtin_fmaxf(nz.x, kNearClamp));
     f0 = __builtin_fminf(__builtin_fminf(fx.x, fy.x), __builtin_fminf(fz.x, cut));
-    n1 = __builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), __builtin_fmaxf(nz.y, 0.0f));
+    n1 = __builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), __builtin_fmaxf(nz.y, kNearClamp));
     f1 = __builtin_fminf(__builtin_fminf(fx.y, fy.y), __builtin_fminf(fz.y, cut));
 }
-RT_DEV void order_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
-    const bool sw = kb < ka;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb; const int32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-    ka = k0; kb = k1; ra = r0; rb = r1;
+RT_DEV void order_keys(double& a, double& b) {                  // (a, b) <- (min, max): exact on the bit patterns of positive normal doubles
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    a = lo; b = hi;
 }
 // Stack rule: the siblings that are not visited next are pushed one by one (far-to-near) while
 //     pending entries + 2 + levels(node) <= budget            (budget = kStackBudget; a test knob can lower it to the level count),
@@ -145,9 +161,14 @@ template <bool COUNT>
 RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, uint32_t& nNode) {
     const bool resumed = cur >= kResumeBase;
     const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
-    const float4* n = nodes + (size_t)node * 4;
-    const float4 q0 = n[0], q1 = n[1], q2 = n[2];
-    const float2 q3 = *reinterpret_cast<const float2*>(n + 3);
+    float4 q0, q1, q2; float2 q3;
+    if ((uint32_t)node < st.topCount) {
+        const float4* n = st.top4 + (size_t)node * 4;
+        q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
+    } else {
+        const float4* n = nodes + (size_t)node * 4;
+        q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
+    }
     const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u, levels = ex >> 27;
     if (COUNT) { nBox += (uint32_t)__popc((resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u)); nNode += 1u; }
     const float Ax = __int_as_float((int)((ex & 0xFFu) << 23)) * r.ix, Ay = __int_as_float((int)(((ex >> 8) & 0xFFu) << 23)) * r.iy,
@@ -170,36 +191,38 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
                  __builtin_elementwise_fma(v2f{ubyte_f(nyq, 2), ubyte_f(nyq, 3)}, Ay2, By2), __builtin_elementwise_fma(v2f{ubyte_f(fyq, 2), ubyte_f(fyq, 3)}, Ay2, By2),
                  __builtin_elementwise_fma(v2f{ubyte_f(nzq, 2), ubyte_f(nzq, 3)}, Az2, Bz2), __builtin_elementwise_fma(v2f{ubyte_f(fzq, 2), ubyte_f(fzq, 3)}, Az2, Bz2),
                  cut, k2, f2, k3, f3_);
-    const float kMissKey = __builtin_inff();
-    k0 = (k0 <= f0) ? k0 : kMissKey;
-    k1 = (k1 <= f1) ? k1 : kMissKey;
-    k2 = (k2 <= f2) ? k2 : kMissKey;
-    k3 = (k3 <= f3_) ? k3 : kMissKey;
+    // Hit children ordered by entry distance: the four (entry distance, child reference) pairs are sorted as 64-bit keys — the distance's
+    // bit pattern in the high word, the reference in the low word — with v_min_f64 / v_max_f64: for positive normal doubles the numeric
+    // order IS the order of the bit patterns, every distance here is >= 1e-30 (the near clamp of slab_of_pair) and no larger than +inf, which
+    // as a high word gives exponent fields between 0x0DA and 0x7F8: normal, finite.  A comparator is two 4-cycle instructions instead of a
+    // compare and four selects (profiles/r03/microbench.jsonl: v_min_f64 4.3 cycles, v_cmp + v_cndmask 4.1 each).  Equal distances
+    // are ordered by the reference (any fixed rule does: the oracle's twin applies the same one).
+    constexpr uint32_t kMissHi = 0x7F900000u;                         // above every distance (+inf = 0x7F800000), still a finite double
+    uint32_t h0 = (k0 <= f0) ? __float_as_uint(k0) : kMissHi;
+    uint32_t h1 = (k1 <= f1) ? __float_as_uint(k1) : kMissHi;
+    uint32_t h2 = (k2 <= f2) ? __float_as_uint(k2) : kMissHi;
+    uint32_t h3 = (k3 <= f3_) ? __float_as_uint(k3) : kMissHi;
     if (__ballot(resumed) != 0ull) {                                  // rare: a resumed visit only looks at the slots still owed
         const uint32_t allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu;
-        k0 = (allow & 1u) ? k0 : kMissKey; k1 = (allow & 2u) ? k1 : kMissKey; k2 = (allow & 4u) ? k2 : kMissKey; k3 = (allow & 8u) ? k3 : kMissKey;
+        h0 = (allow & 1u) ? h0 : kMissHi; h1 = (allow & 2u) ? h1 : kMissHi; h2 = (allow & 4u) ? h2 : kMissHi; h3 = (allow & 8u) ? h3 : kMissHi;
     }
-    const float s0 = k0, s1 = k1, s2 = k2, s3 = k3;                   // keys by slot, before the sort
-    int32_t r0 = __float_as_int(q1.x), r1 = __float_as_int(q1.y), r2 = __float_as_int(q1.z), r3 = __float_as_int(q1.w);
-    order_pair(k0, r0, k1, r1); order_pair(k2, r2, k3, r3); order_pair(k0, r0, k2, r2); order_pair(k1, r1, k3, r3); order_pair(k1, r1, k2, r2);
+    const int32_t c0 = __float_as_int(q1.x), c1 = __float_as_int(q1.y), c2 = __float_as_int(q1.z), c3 = __float_as_int(q1.w);
+    double d0 = __hiloint2double((int)h0, c0), d1 = __hiloint2double((int)h1, c1), d2 = __hiloint2double((int)h2, c2), d3 = __hiloint2double((int)h3, c3);
+    order_keys(d0, d1); order_keys(d2, d3); order_keys(d0, d2); order_keys(d1, d3); order_keys(d1, d2);
+    const uint32_t s0h = (uint32_t)__double2hiint(d0), s1h = (uint32_t)__double2hiint(d1), s2h = (uint32_t)__double2hiint(d2), s3h = (uint32_t)__double2hiint(d3);
+    const int32_t r0 = __double2loint(d0), r1 = __double2loint(d1), r2 = __double2loint(d2), r3 = __double2loint(d3);
     if ((st.top - 1) + 2 + (int)levels <= budget) {
         // unconditional stores, conditional advance: three ds_write_b32 without a branch each (entries top .. top + 2 exist: the
         // rule above leaves room for them; a slot written for a child that was not hit is simply overwritten by the next push)
-#ifdef RT_COND_PUSH
-        if (k3 < kMissKey) st.push(r3);
-        if (k2 < kMissKey) st.push(r2);
-        if (k1 < kMissKey) st.push(r1);
-#else
-        st.lds[st.top * kBlock] = r3; st.top += (k3 < kMissKey) ? 1 : 0;
-        st.lds[st.top * kBlock] = r2; st.top += (k2 < kMissKey) ? 1 : 0;
-        st.lds[st.top * kBlock] = r1; st.top += (k1 < kMissKey) ? 1 : 0;
-#endif
-    } else if (k1 < kMissKey) {                                      // two or more hits and no room to push them one by one
-        const uint32_t hit = (s0 < kMissKey ? 1u : 0u) | (s1 < kMissKey ? 2u : 0u) | (s2 < kMissKey ? 4u : 0u) | (s3 < kMissKey ? 8u : 0u);
-        const uint32_t nearest = (s0 == k0) ? 1u : (s1 == k0) ? 2u : (s2 == k0) ? 4u : 8u;   // the sort keeps slot order on ties
+        st.lds[st.top * kBlock] = r3; st.top += (s3h < kMissHi) ? 1 : 0;
+        st.lds[st.top * kBlock] = r2; st.top += (s2h < kMissHi) ? 1 : 0;
+        st.lds[st.top * kBlock] = r1; st.top += (s1h < kMissHi) ? 1 : 0;
+    } else if (s1h < kMissHi) {                                      // two or more hits and no room to push them one by one
+        const uint32_t hit = (h0 < kMissHi ? 1u : 0u) | (h1 < kMissHi ? 2u : 0u) | (h2 < kMissHi ? 4u : 0u) | (h3 < kMissHi ? 8u : 0u);
+        const uint32_t nearest = (c0 == r0) ? 1u : (c1 == r0) ? 2u : (c2 == r0) ? 4u : 8u;     // the nearest child's slot (references of hit slots are distinct)
         st.push(kResumeBase + (int32_t)(((uint32_t)node << 4) | (hit & ~nearest)));
     }
-    return (k0 < kMissKey) ? r0 : st.pop();
+    return (s0h < kMissHi) ? r0 : st.pop();
 }
 
 // A ray with a NaN or infinite component can hit no triangle (every Möller–Trumbore comparison fails), but its slab tests
@@ -248,13 +271,13 @@ RT_DEV float light_tri_distance(const DevScene& sc, uint32_t tri, f3 o, f3 d) {
 // Ordered traversal (nearest hit child first, the others pushed far-to-near), boxes culled against closest * 1.000001f; a
 // triangle is accepted when 1e-4 < t < closest, no back-face culling.
 template <bool COUNT>
-RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
+RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase, const float4* top4 = nullptr) {
     Hit h; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.tri = -1;
     uint32_t nBox = 0, nTri = 0, nNode = 0;
     if (sc.triCount == 0 || ray_not_finite(o, d)) { if (COUNT) atomicAdd(sc.rayCounter, 1ull); return h; }
     const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     float closestInfl = h.t * 1.000001f;
-    Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
+    Stack st; st.lds = ldsBase; st.top = 0; st.top4 = top4; st.topCount = top4 ? sc.topCount : 0u; st.push(kExit);
     int32_t cur = sc.rootRef;
     while (true) {
         while (cur >= 0) {
@@ -291,19 +314,19 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
 // "not closer" (the reference's own tie order is traversal-order dependent).
 struct ShadowHit { float hitDistance; int32_t objectIndex; };
 template <bool COUNT>
-RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri, int32_t* ldsBase) {
+RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri, int32_t* ldsBase, const float4* top4 = nullptr) {
     ShadowHit r;
     const float tL = light_tri_distance(sc, lightTri, o, d);
     if (!(tL > 0.0f)) {                               // light not hit by its own shadow ray: exact fallback
         if (COUNT) atomicAdd(sc.rayCounter + 2, 1ull);
-        const Hit h = trace_closest<COUNT>(sc, o, d, ldsBase);
+        const Hit h = trace_closest<COUNT>(sc, o, d, ldsBase, top4);
         r.hitDistance = (h.tri < 0) ? -1.0f : h.t; r.objectIndex = h.tri;
         return r;
     }
     uint32_t nBox = 0, nTri = 1, nNode = 0;
     const RayPk pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     const float cut = tL * 1.000001f;
-    Stack st; st.lds = ldsBase; st.top = 0; st.push(kExit);
+    Stack st; st.lds = ldsBase; st.top = 0; st.top4 = top4; st.topCount = top4 ? sc.topCount : 0u; st.push(kExit);
     int32_t cur = sc.rootRef;
     r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
     bool occluded = false;
@@ -349,8 +372,8 @@ RT_DEV Payload make_hit(const DevScene& sc, f3 o, f3 d, const Hit& h) {
     return p;
 }
 template <bool COUNT>
-RT_DEV Payload trace_ray(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase) {
-    const Hit h = trace_closest<COUNT>(sc, o, d, ldsBase);
+RT_DEV Payload trace_ray(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase, const float4* top4 = nullptr) {
+    const Hit h = trace_closest<COUNT>(sc, o, d, ldsBase, top4);
     return (h.tri < 0) ? make_miss() : make_hit(sc, o, d, h);
 }
 

@@ -239,7 +239,8 @@ RT_DEV uint32_t neighbor_index(const DevCamera& cam, uint32_t W, uint32_t x, uin
 // epilogue only inside the band proper so halo rows never touch accumulation.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, uint32_t p1Begin, uint32_t p1End, uint32_t extraRow) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch, + the top-node copy
+    const float4* top4 = stage_top_nodes(sc.nodes, sc.topCount, sc.stackBudget, s_stack);
     uint32_t x, y;
     if (!p1_pixel_of_thread(fr, p1Begin, p1End, extraRow, x, y)) return;
     int32_t* stk = s_stack + threadIdx.x;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_di_part1(DevScene sc, DevCamera cam,
     const bool inBand = (y >= fr.rowBegin && y < fr.rowEnd);
     uint32_t seed = i * (fr.frameIndex + 1u + st.randSeed);
     const f3 pd = ray_direction(cam, x, y);
-    const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, stk);
+    const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, stk, top4);
     fr.payload[i] = pp;
     const f2 ncur = oct_encode(nrm3(pp));
     DIRes R = di_empty();

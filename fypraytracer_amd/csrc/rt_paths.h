@@ -33,7 +33,9 @@ struct PathIO {
     uint32_t* part2List; uint32_t* part2Count;                                // ReSTIR GI: pixels that continue into Part 2; NEE: the PICK list (counter = countOut)
     uint32_t* misList; uint32_t* misCount;                                    // NEE: paths whose BRDF ray hit an emitter
     const uint32_t* ownersIn; uint32_t* ownersOut;                            // ReSTIR GI Part 2: the entries' pixels as a list of their own (its steps do not read the ray records)
+    uint32_t fusedOwner;                                                      // k_path_fused: the thread's own pixel (step 0 has no list to read it from); kNotFused otherwise
 };
+constexpr uint32_t kNotFused = 0xFFFFFFFFu;
 
 struct RayRec { float4 q0, q1, q2; };
 RT_DEV RayRec ray_closest(f3 o, f3 d, uint32_t pixel) {
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene sc, DevCamera cam, 
 }
 
 RT_DEV uint32_t owner_of(const PathIO& io, uint32_t j) {
+    if (io.fusedOwner != kNotFused) return io.fusedOwner;
     return io.iteration == 0u ? io.pixelList[j] : (uint32_t)__float_as_int(io.raysIn[(size_t)j * io.raysPer * 3].w);
 }
 
@@ -589,6 +592,51 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     fr.giPrev[i] = R;
     epilogue(fr, i, rgb1(radiance));
     return false;
+}
+
+// ============================================================ small scenes: the whole frame of techniques 0-5 in ONE launch
+// A scene whose rays cost a handful of node visits (Cornell box: 3; the reference's banana: 8) gains nothing from re-packing lanes
+// between bounces, and every one of the 2 x steps + 1 stage launches pays its own fill, drain and one-wave-round latency: the
+// Cornell frame of BASELINE config 1 took 0.21 ms in ten launches against 0.11 ms for one thread per pixel.  This
+// kernel is that one thread per pixel again — primary ray, then the SAME step functions (path_step / light_step: same expressions, same
+// random draws, same order of additions) with the same one-thread-per-ray traversal (trace_one) in between — so its pixels are the stage
+// path's bit for bit (tests/test_gpu_tuning.py).  The step functions keep their state where the stages keep it (PathIO::state, the ray
+// and hit records at the thread's own slot): a thread reads back what it has written itself.  Chosen by the host for trees of fewer
+// than 64 k triangles (tuning key 17).
+template <int TECH, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_path_fused(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, PathIO io, uint32_t steps) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    uint32_t x, y;
+    bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);
+    const uint32_t j = (y - fr.rowBegin) * fr.W + x;             // the thread's slot in the ray / hit records: its pixel's index inside the band (local rows of a striped frame)
+    if (fr.stripeRows != 0u) {
+        const uint32_t k = y / fr.stripeRows;
+        y = (k * fr.stripeParts + fr.stripePart) * fr.stripeRows + (y - k * fr.stripeRows);
+        inside = inside && y < fr.H;
+    }
+    const uint32_t i = x + y * fr.W;
+    bool live = false;
+    if (inside) {
+        const f3 pd = ray_direction(cam, x, y);
+        const Payload pp = trace_ray<COUNT>(sc, cam.position, pd, s_stack + threadIdx.x);
+        fr.payload[i] = pp;
+        if (pp.hitDistance < 0.0f) epilogue(fr, i, rgb1(st.sky));
+        else {
+            const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
+            if (length(emission(hm)) > 0.0f) epilogue(fr, i, rgb1(emission(hm))); else live = true;
+        }
+    }
+    io.fusedOwner = i;
+    for (uint32_t it = 0; live && it <= steps; ++it) {
+        io.iteration = it;
+        RayRec r;
+        live = (TECH == T_LIGHT) ? light_step(sc, cam, fr, st, io, j, r) : path_step<(TECH <= T_BRDF ? TECH : T_BRUTE)>(sc, cam, fr, st, io, j, r);
+        if (!live) break;
+        store_ray(io.raysOut, j, r);
+        const float4 h = trace_one<COUNT>(sc, xyz(r.q0), xyz(r.q1), (uint32_t)__float_as_int(r.q1.w), r.q2.x, r.q2.y, s_stack + threadIdx.x);
+        const_cast<float4*>(io.hitsIn)[j] = h;
+        __threadfence_block();                                   // the thread's own stores are complete before the next step loads them
+    }
 }
 
 // ============================================================ the shade kernel: one thread per live path, grid-stride over the list

@@ -308,6 +308,7 @@ RT_DEV int32_t lane_pop(int32_t* lds, int& top) { --top; return lds[top * kBlock
 template <bool COUNT>
 RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const ShadowQueue& q, int32_t* s_stack) {
     int32_t* lds = s_stack + threadIdx.x;
+    const float4* top4 = stage_top_nodes(sc.nodes, sc.topCount, sc.stackBudget, s_stack);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = q.counters[0];
     // Work distribution: every wave owns the first `first` tasks of its own slice statically (wave w: [w * first, (w + 1) * first)),
@@ -386,7 +387,7 @@ RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const Sh
         while (true) {
             // inner nodes
             while (active && r.cur >= 0) {
-                { Stack st; st.lds = lds; st.top = r.top; r.cur = node_step<COUNT>(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, r.nNode); r.top = st.top; }
+                { Stack st; st.lds = lds; st.top = r.top; st.top4 = top4; st.topCount = sc.topCount; r.cur = node_step<COUNT>(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, r.nNode); r.top = st.top; }
                 if ((uint32_t)__popcll(__ballot(r.cur >= 0)) < sc.nodeQuorum) break;
             }
             // leaves

@@ -353,11 +353,18 @@ void fyprt_comm_destroy(fyprt_context* ctx);
 /* The two parts of a ReSTIR frame as separate asynchronous calls, for a host with its own transport for the halo rows. */
 int fyprt_render_part(fyprt_context* ctx, const fyprt_settings* settings, int part /* 1 or 2 */);
 /* Cost-balanced bands: new boundaries from the milliseconds each band took (fyprt_last_frame_ms), at most `max_shift` rows per
- * boundary and call, bands at least `min_rows` high.  Rows that change owner lose their temporal history. */
+ * boundary and call, bands at least `min_rows` high.  Pure arithmetic: the rows change owner with fyprt_group_set_rows /
+ * fyprt_comm_set_rows, which move their accumulation and temporal history along. */
 int fyprt_balance_rows(const uint32_t* row_bounds, const float* band_ms, int n, uint32_t min_rows, uint32_t max_shift, uint32_t* new_bounds);
 int fyprt_last_frame_ms(fyprt_context* ctx, float* ms);
 /* The transfers of one halo exchange: (receiver, owner, first row, end row) per entry; returns the number of entries. */
 int fyprt_halo_plan(const uint32_t* row_bounds, int n, uint32_t halo, uint32_t height, int wrap_row, uint32_t* out4, int capacity);
+/* The point-to-point operations rank `rank` issues inside ONE RCCL group section, in issue order — kind 0: a halo exchange over
+ * `row_bounds`; kind 1: fyprt_comm_set_rows from `row_bounds` to `new_bounds`.  (is_recv, peer, buffer, byte offset, bytes) per
+ * operation; returns their number.  Pure host arithmetic (no device, no RCCL): lets a test check that the two ends of every pair of
+ * ranks list the same byte counts in the same order, which is what RCCL's matching needs. */
+int fyprt_comm_ops(int kind, const uint32_t* row_bounds, const uint32_t* new_bounds, int n, uint32_t halo, uint32_t height, int wrap_row, uint32_t width,
+                   int rank, const uint32_t* bytes_per_pixel, int nbuf, uint64_t* out5, int capacity);
 
 /* Library / build identification ("fyprt <version> gfx950 ..."). */
 const char* fyprt_version(void);

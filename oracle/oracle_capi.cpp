@@ -90,6 +90,10 @@ void orc_set_product_bvh(orc_handle* h, const void* nodes, uint32_t nodeCount, c
 // deepest traversal stack the product-order restatement has used so far, and a knob to force its resume-entry path
 int orc_product_max_stack(orc_handle* h) { return h->prodTracer->maxTop; }
 void orc_set_product_stack_budget(orc_handle* h, int budget) { h->prodTracer->stackBudget = budget; }
+// event log of the product-order traversal (tools/wave_sim.py): start with on = 1 (render with ONE thread), read with orc_take_events
+static std::vector<uint8_t> g_events;
+void orc_record_events(orc_handle* h, int on) { g_events.clear(); h->prodTracer->events = on ? &g_events : nullptr; }
+size_t orc_take_events(orc_handle* h, uint8_t* dst, size_t cap) { (void)h; if (dst) std::memcpy(dst, g_events.data(), g_events.size() < cap ? g_events.size() : cap); return g_events.size(); }
 void orc_set_camera(orc_handle* h, const orc_camera_desc* c) {
     Camera cam;
     cam.projection = mat4_from(c->projection); cam.view = mat4_from(c->view);

@@ -13,9 +13,9 @@
 //   tri   (48 B): float v0[3], e1[3], e2[3]; uint32 triangleIndex; uint32 pad[2]
 // Traversal: per visit A_a = 2^(ex_a-127) * (1/d_a), B_a = (origin_a - o_a) * (1/d_a), slab parameter of a plane
 // t = fma(q, A_a, B_a), entry plane = lo where 1/d_a >= 0 else hi (unused slots hold lo 255 / hi 0 and never pass);
-// children culled against cut (= closest*1.000001f, or the light / visibility distance); hit
-// children ordered by entry distance with the 5-comparator network (0,1)(2,3)(0,2)(1,3)(1,2), strict "<" so ties keep
-// slot order; nearest visited next, the others pushed far-to-near; |d| < 1e-30 replaced by copysign(1e-30, d);
+// children culled against cut (= closest*1.000001f, or the light / visibility distance), the entry distance clamped to >= 1e-30; hit
+// children ordered by the 64-bit key (entry distance bits << 32 | child reference) with the 5-comparator network
+// (0,1)(2,3)(0,2)(1,3)(1,2) — equal distances go by reference; nearest visited next, the others pushed far-to-near; |d| < 1e-30 replaced by copysign(1e-30, d);
 // Möller–Trumbore identical to Renderer.cu:513-537 on (v0, e1, e2).
 #pragma once
 #include "oracle_render.h"
@@ -51,7 +51,10 @@ struct ProductTracer : Tracer {
         const float o[3] = {ox, oy, oz}, inv[3] = {ix, iy, iz};
         float A[3], B[3];
         for (int a = 0; a < 3; ++a) { A[a] = pow2e(n.ex[a]) * inv[a]; B[a] = (n.origin[a] - o[a]) * inv[a]; }
-        float key[4], slotKey[4]; int32_t ref[4];
+        // sort keys: (bit pattern of the entry distance, child reference) as one unsigned 64-bit number — what the product's
+        // v_min_f64 / v_max_f64 network orders (numeric order of positive normal doubles = order of their bit patterns)
+        constexpr uint32_t kMissHi = 0x7F900000u;
+        uint64_t key[4]; uint32_t slotHi[4];
         for (int i = 0; i < 4; ++i) {
             float tn[3], tf[3];       // entry through the lo plane where the ray travels in +axis direction, else through the hi plane
             for (int a = 0; a < 3; ++a) {
@@ -59,29 +62,36 @@ struct ProductTracer : Tracer {
                 tn[a] = fmaf((float)(neg ? n.qhi[a][i] : n.qlo[a][i]), A[a], B[a]);
                 tf[a] = fmaf((float)(neg ? n.qlo[a][i] : n.qhi[a][i]), A[a], B[a]);
             }
-            float tnear = fmaxf(fmaxf(tn[0], tn[1]), fmaxf(tn[2], 0.0f));
+            float tnear = fmaxf(fmaxf(tn[0], tn[1]), fmaxf(tn[2], 1e-30f));      // the product's kNearClamp
             float tfar = fminf(fminf(tf[0], tf[1]), fminf(tf[2], cut));
-            key[i] = slotKey[i] = (tnear <= tfar && ((allow >> i) & 1u)) ? tnear : INFINITY;   // unused slots (lo 255, hi 0) never pass
-            ref[i] = n.child[i];
+            uint32_t hi; memcpy(&hi, &tnear, 4);
+            slotHi[i] = (tnear <= tfar && ((allow >> i) & 1u)) ? hi : kMissHi;   // unused slots (lo 255, hi 0) never pass
+            key[i] = ((uint64_t)slotHi[i] << 32) | (uint32_t)n.child[i];
         }
-        auto order = [&](int a, int b) { if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(ref[a], ref[b]); } };
+        auto order = [&](int a, int b) { if (key[b] < key[a]) std::swap(key[a], key[b]); };
         order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+        auto hiOf = [&](int i) { return (uint32_t)(key[i] >> 32); };
+        auto refOf = [&](int i) { return (int32_t)(uint32_t)key[i]; };
         if (top + 2 + (int)levels <= stackBudget) {
-            if (key[3] < INFINITY) stack[top++] = ref[3];
-            if (key[2] < INFINITY) stack[top++] = ref[2];
-            if (key[1] < INFINITY) stack[top++] = ref[1];
-        } else if (key[1] < INFINITY) {
+            if (hiOf(3) < kMissHi) stack[top++] = refOf(3);
+            if (hiOf(2) < kMissHi) stack[top++] = refOf(2);
+            if (hiOf(1) < kMissHi) stack[top++] = refOf(1);
+        } else if (hiOf(1) < kMissHi) {
             uint32_t hit = 0, nearest = 8;
-            for (int i = 0; i < 4; ++i) if (slotKey[i] < INFINITY) hit |= 1u << i;
-            for (int i = 0; i < 4; ++i) if (slotKey[i] == key[0]) { nearest = 1u << i; break; }
+            for (int i = 0; i < 4; ++i) if (slotHi[i] < kMissHi) hit |= 1u << i;
+            for (int i = 0; i < 4; ++i) if (n.child[i] == refOf(0)) { nearest = 1u << i; break; }
             stack[top++] = kResumeBase + (int32_t)(((uint32_t)node << 4) | (hit & ~nearest));
         }
         maxTop = top > maxTop ? top : maxTop;
-        if (key[0] < INFINITY) { next = ref[0]; return true; }
+        if (hiOf(0) < kMissHi) { next = refOf(0); return true; }
         return false;
     }
     int stackBudget = 31;       // the product's tuning key 8
     mutable int maxTop = 0;     // deepest stack seen (diagnostic; racy across OpenMP threads, only ever compared with 31)
+    // Event log for tools/wave_sim.py (scheduling studies of the persistent trace kernels; single-threaded renders only): per ray
+    // 0xF0 | kind (0 closest, 1 shadow, 2 visibility), then 0x01 per node visit and 0x10 | n per leaf with n triangle tests executed, 0xFF at its end.
+    mutable std::vector<uint8_t>* events = nullptr;
+    inline void ev(uint8_t b) const { if (events) events->push_back(b); }
     Payload Trace(const Ray& ray, Counters& c) const override {
         c.rays++;
         if (tris.empty() || notFinite(ray)) return Miss();
@@ -89,12 +99,15 @@ struct ProductTracer : Tracer {
         const float ix = safeInv(ray.direction.x), iy = safeInv(ray.direction.y), iz = safeInv(ray.direction.z);
         float closest = FLT_MAX, closestInfl = closest * 1.000001f; int closestTri = -1; float cu = 0.0f, cv = 0.0f;
         int32_t stack[128]; int top = 0; int32_t cur = rootRef;
+        ev(0xF0);
         while (true) {
             if (cur >= 0) {
+                ev(0x01);
                 if (Visit(cur, ox, oy, oz, ix, iy, iz, closestInfl, stack, top, cur, c)) continue;
             } else {
                 if (cur == INT32_MIN) break;                       // the product's exit sentinel (an unused child slot holds it)
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+                ev((uint8_t)(0x10 | cnt));
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const PTri& T = tris[first + k];
                     c.triTests++;
@@ -114,6 +127,7 @@ struct ProductTracer : Tracer {
             if (top == 0) break;
             cur = stack[--top];
         }
+        ev(0xFF);
         if (closestTri < 0) return Miss();
         c.hits++;
         return ClosestHit(sc, ray, closest, closestTri, cu, cv);
@@ -143,16 +157,19 @@ struct ProductTracer : Tracer {
         const float cut = tL * 1.000001f;
         int32_t stack[128]; int top = 0; int32_t cur = rootRef;
         Payload r = Miss(); r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
+        ev(0xF1);
         while (true) {
             if (cur >= 0) {
+                ev(0x01);
                 if (Visit(cur, ox, oy, oz, ix, iy, iz, cut, stack, top, cur, c)) continue;
             } else {
                 if (cur == INT32_MIN) break;                       // the product's exit sentinel (an unused child slot holds it)
                 uint32_t code = (uint32_t)~cur; uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+                const size_t evAt = events ? events->size() : 0; ev(0x10);
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const PTri& T = tris[first + k];
                     if (T.tri == lightTri) continue;
-                    c.triTests++;
+                    c.triTests++; if (events) (*events)[evAt]++;
                     vec3 v0 = v3(T.v0[0], T.v0[1], T.v0[2]), e1 = v3(T.e1[0], T.e1[1], T.e1[2]), e2 = v3(T.e2[0], T.e2[1], T.e2[2]);
                     vec3 h = cross(ray.direction, e2);
                     float a = dot(e1, h), f = 1.0f / a;
@@ -163,12 +180,13 @@ struct ProductTracer : Tracer {
                     float v = f * dot(ray.direction, q);
                     if (v < 0.0f || (u + v) > 1.0f) continue;
                     float t = f * dot(e2, q);
-                    if (t > 0.0001f && t < tL) { r.hitDistance = t; r.objectIndex = (int32_t)T.tri; return r; }
+                    if (t > 0.0001f && t < tL) { r.hitDistance = t; r.objectIndex = (int32_t)T.tri; ev(0xFF); return r; }
                 }
             }
             if (top == 0) break;
             cur = stack[--top];
         }
+        ev(0xFF);
         return r;
     }
     // Restatement of the product's trace_visible (rt_device.h): interval cut at dist + tol, early "not visible" on any hit

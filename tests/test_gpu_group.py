@@ -151,6 +151,34 @@ def test_rccl_communicator_of_one_rank():
     ctx.close()
 
 
+def test_comm_set_rows_between_pipelined_frames():
+    """fyprt_comm_set_rows between ASYNCHRONOUS (pipelined) ReSTIR DI frames: the front stream may still run Part 1 + setup of a frame when
+    the call arrives; it must drain the context before it touches the history rows and return with them in place.  With
+    one rank no row moves, so the sequence must stay the single-context sequence bit for bit."""
+    mk_scene, mk_cam = SCENES["cornell"]
+    sc, W, H = mk_scene(), 96, 80
+    cam = mk_cam(W, H)
+    ctx = _contexts(1, sc, cam, W, H)[0]
+    lib = ctx.lib
+    uid = (C.c_char * 128)()
+    assert lib.fyprt_comm_unique_id(uid) == 0, lib.fyprt_last_error(None)
+    bounds = (C.c_uint32 * 2)(0, H)
+    ctx._check(lib.fyprt_comm_init_rank(ctx.h, 1, 0, uid, bounds))
+    st = settings_for(capi.RESTIR_DI)
+    frames = 6
+    ref = _single(sc, cam, W, H, capi.RESTIR_DI, frames)[-1]
+    for f in range(frames):
+        st.rand_seed = f + 1
+        ctx._check(lib.fyprt_comm_render(ctx.h, C.byref(st)))          # recompute mode, one rank: a plain pipelined frame
+        if f in (1, 2, 4):
+            ctx._check(lib.fyprt_comm_set_rows(ctx.h, bounds))           # no synchronize in between
+    ctx.synchronize()
+    img, acc = ctx.readback()
+    assert np.array_equal(img, ref[0]) and bits_equal(acc, ref[1]).all()
+    lib.fyprt_comm_destroy(ctx.h)
+    ctx.close()
+
+
 def test_asynchronous_frames_with_a_gather_per_frame():
     """No synchronisation between frames: the next frame's epilogues must not overwrite a band the root's gather is still copying, the
     halo pulls of frame N+1 must not overtake frame N.  The frame gathered at the end is the single-context frame."""

@@ -49,6 +49,36 @@ def test_knobs_do_not_change_results(tech):
             assert np.array_equal(acc, ref[1], equal_nan=True), knobs
 
 
+@pytest.mark.parametrize("scene_name", ["cornell", "banana"])
+@pytest.mark.parametrize("tech", [capi.BRUTE_FORCE, capi.UNIFORM_SAMPLING, capi.COSINE_WEIGHTED_SAMPLING, capi.GGX_SAMPLING, capi.BRDF_SAMPLING, capi.LIGHT_SOURCE_SAMPLING])
+def test_fused_small_scene_frame_equals_the_stage_frame(scene_name, tech):
+    """Techniques 0-5 on a small tree run as ONE launch (k_path_fused, tuning key 17 = 2 / auto) — the same step functions as the
+    wavefront stages (key 17 = 1) with the traversal in between: every pixel, and every instrumentation count, must be the stages'."""
+    mk_scene, mk_cam = SCENES[scene_name]
+    sc, W, H = mk_scene(), 120, 88                   # not a multiple of 16: partial tiles
+    cam = mk_cam(W, H)
+    outs = []
+    for mode in (1, 2, 0):                           # stages, fused, auto (= fused: both scenes are far below 64 k triangles)
+        ctx = capi.Context(0)
+        ctx.resize(W, H)
+        ctx.upload_scene(sc)
+        ctx.set_camera(cam)
+        ctx.set_tuning(17, mode)
+        ctx.set_ray_counting(True)
+        st = settings_for(tech, light_bounces=3, sample_count=2)
+        counts = []
+        for f in range(3):
+            st.rand_seed = f + 1
+            s = ctx.render(st)
+            counts.append((s.rays, s.box_tests, s.tri_tests, s.hits, s.node_visits))
+            assert s.launches == 1
+        outs.append((ctx.readback(), counts))
+        ctx.close()
+    for (img, acc), counts in outs[1:]:
+        assert np.array_equal(img, outs[0][0][0]) and np.array_equal(acc, outs[0][0][1], equal_nan=True)
+        assert counts == outs[0][1]
+
+
 def test_async_frames_equal_blocking_frames():
     mk_scene, mk_cam = SCENES["cornell"]
     sc, W, H = mk_scene(), 96, 96
@@ -140,7 +170,7 @@ def test_light_sorted_tasks_with_pipelined_async_frames():
 
 def test_tuning_values_are_range_checked():
     ctx = capi.Context(0)
-    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 0), (-1, 0)):
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (24, 0), (-1, 0)):
         with pytest.raises(capi.FyprtError):
             ctx.set_tuning(key, bad)
     ctx.set_tuning(5, 64)

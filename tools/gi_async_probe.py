@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Asynchronous ReSTIR GI frames at 4K on the 1 M-triangle hall: host enqueue time per frame against wall time per frame (are the frames
+really asynchronous?) and the per-part kernel times of the last frames.   usage: python tools/gi_async_probe.py   (FYPRT_LIB=<alternative libfyprt.so>)"""
 import sys, time
-sys.path.insert(0,'/root/repo')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 from fypraytracer_amd import capi, scenes
 W,H=3840,2160
