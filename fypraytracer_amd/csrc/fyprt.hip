@@ -759,7 +759,11 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
     // and more workgroups fit a CU (LDS is what limits residency: (budget + 1) KB per 256-thread workgroup)
     const int budget = effective_stack_budget(c);
     c->dsc.stackBudget = budget;
+#ifdef RT_TOPCACHE
     c->dsc.topCount = (uint32_t)std::min<size_t>((size_t)std::max(0, c->tuning[16]), c->hostBvh.nodes.size());
+#else
+    c->dsc.topCount = 0u;                      // tuning key 16 only acts in a -DRT_TOPCACHE build (rt_device.h: measured slower)
+#endif
     const size_t ldsBytes = (size_t)(budget + 1) * kBlock * sizeof(int32_t) + (size_t)c->dsc.topCount * 64u;
     // Pipelining (tuning key 11): a wavefront ReSTIR DI frame runs Part 1 + setup on the front stream and the trace kernel on
     // `stream`.  Nothing the front part writes is read or written by a trace kernel (payload, records, history, depth, its own

@@ -11,12 +11,14 @@
 //     device importance code reads that centroid (LightTree.cuh:101-105).
 // Leaves: Mesh::CreateLightTreenodesFromEmmisiveMeshTriangles (Mesh.cpp:176-207); TLAS leaves:
 // Scene::CreateLightTreeNodesFromBLASLightTrees (Scene.cpp:160-186).
-// Host-only arithmetic (std::acos / cos / sin of the C library), fp-contract off.
+// Host-only arithmetic, fp-contract off; acos / cos / sin are the deterministic binary64 routines of rt_hostmath.h (the device's own
+// algorithms), NOT the C library's: the trees are the same bits on every host.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include "rt_host.h"
+#include "rt_hostmath.h"
 
 namespace rth {
 namespace {
@@ -45,7 +47,7 @@ inline float axisOf(const V3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : 
 
 // glm::rotate(mat4(1), angle, axis) * vec4(v, 0)
 V3 rotateAbout(V3 v, float angle, V3 axisIn) {
-    const float c = std::cos(angle), s = std::sin(angle);
+    float c, s; det_sincos(angle, s, c);
     const V3 a = norm3(axisIn), t = a * (1.0f - c);
     const V3 c0{c + t.x * a.x, t.x * a.y + s * a.z, t.x * a.z - s * a.y};
     const V3 c1{t.y * a.x - s * a.z, c + t.y * a.y, t.y * a.z + s * a.x};
@@ -55,7 +57,7 @@ V3 rotateAbout(V3 v, float angle, V3 axisIn) {
 }
 Cone uniteCones(Cone a, Cone b) {                                   // ConeBounds::UnionCone
     if (b.to > a.to) std::swap(a, b);
-    const float td = std::acos(dot3(a.axis, b.axis));
+    const float td = det_acos(dot3(a.axis, b.axis));
     const float te = std::fmax(a.te, b.te);
     if (std::fmin(td + b.to, kPi) <= a.to) return {a.axis, a.to, te};
     const float to = (a.to + td + b.to) * 0.5f;
@@ -66,8 +68,8 @@ Cone uniteCones(Cone a, Cone b) {                                   // ConeBound
 float orientMeasure(float to, float te) {                           // LightTree.cpp:318-329
     const float piHalf = 0.5f * kPi;
     const float tw = std::fmin(to + te, kPi);
-    const float a = (2 * kPi) * (1 - std::cos(to));
-    const float b = piHalf * (2 * tw * std::sin(to) - std::cos(to - 2 * tw) - (2 * to * std::sin(to)) + std::cos(to));
+    const float a = (2 * kPi) * (1 - det_cos(to));
+    const float b = piHalf * (2 * tw * det_sin(to) - det_cos(to - 2 * tw) - (2 * to * det_sin(to)) + det_cos(to));
     return a + b;
 }
 

@@ -103,9 +103,10 @@ constexpr int32_t kExit = (int32_t)0x80000000;
 struct Stack {
     int32_t* lds;                 // &shared[threadIdx.x]
     int top;
-    // LDS copy of the first `topCount` nodes of the array (the builder orders nodes by decreasing box area, so these are the nodes a
-    // ray is most likely to visit: 128 of the bench tree's 194 k nodes take a third of all visits): a visit of one of them costs three
-    // ds_read_b128 instead of four vector-L1 look-ups per lane — the look-up rate of the vector L1 is what bounds the trace kernels
+    // EXPERIMENT (-DRT_TOPCACHE, off by default): an LDS copy of the first `topCount` nodes of the array (the builder orders nodes by decreasing
+    // box area: 64 of the bench tree's 194 k nodes take 32 % of all visits, 256 take 40 %), read with ds_read_b128 instead of vector-L1
+    // look-ups.  Measured (profiles/README.md r03): with 64 nodes the two traversal kernels gain 2 %, but the extra branch of every node
+    // visit costs 4 % — also when the count is zero — because the kernels are bound by vector-instruction issue, not by the L1.
     const float4* top4 = nullptr; uint32_t topCount = 0;
     RT_DEV void push(int32_t v) { lds[top * kBlock] = v; ++top; }
     RT_DEV int32_t pop() { --top; return lds[top * kBlock]; }
@@ -113,10 +114,14 @@ struct Stack {
 
 // workgroup prologue of a traversal kernel: the LDS copy of the hottest nodes behind the (budget + 1) x kBlock stack entries
 RT_DEV const float4* stage_top_nodes(const float4* nodes, uint32_t topCount, int32_t budget, int32_t* s_stack) {
+#ifdef RT_TOPCACHE
     float4* dst = reinterpret_cast<float4*>(s_stack + (size_t)(budget + 1) * kBlock);
     for (uint32_t k = threadIdx.x; k < topCount * 4u; k += (uint32_t)kBlock) dst[k] = nodes[k];
     __syncthreads();
     return dst;
+#else
+    return nullptr;
+#endif
 }
 
 // One visit of a 4-wide node (layout: rt_host.h).  The child planes are never materialised: with the grid step s_a = 2^(e_a-127)
@@ -162,10 +167,13 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     const bool resumed = cur >= kResumeBase;
     const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
     float4 q0, q1, q2; float2 q3;
+#ifdef RT_TOPCACHE
     if ((uint32_t)node < st.topCount) {
         const float4* n = st.top4 + (size_t)node * 4;
         q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
-    } else {
+    } else
+#endif
+    {
         const float4* n = nodes + (size_t)node * 4;
         q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
     }
@@ -207,10 +215,16 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
         h0 = (allow & 1u) ? h0 : kMissHi; h1 = (allow & 2u) ? h1 : kMissHi; h2 = (allow & 4u) ? h2 : kMissHi; h3 = (allow & 8u) ? h3 : kMissHi;
     }
     const int32_t c0 = __float_as_int(q1.x), c1 = __float_as_int(q1.y), c2 = __float_as_int(q1.z), c3 = __float_as_int(q1.w);
+#ifdef RT_SORT_CNDMASK      // timing experiment only (compare + four selects per comparator, ties in slot order: NOT the oracle twin's order)
+    uint32_t s0h = h0, s1h = h1, s2h = h2, s3h = h3; int32_t r0 = c0, r1 = c1, r2 = c2, r3 = c3;
+    auto cs = [](uint32_t& ka, int32_t& ra, uint32_t& kb, int32_t& rb) { const bool sw = kb < ka; const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb; const int32_t x0 = sw ? rb : ra, x1 = sw ? ra : rb; ka = k0; kb = k1; ra = x0; rb = x1; };
+    cs(s0h, r0, s1h, r1); cs(s2h, r2, s3h, r3); cs(s0h, r0, s2h, r2); cs(s1h, r1, s3h, r3); cs(s1h, r1, s2h, r2);
+#else
     double d0 = __hiloint2double((int)h0, c0), d1 = __hiloint2double((int)h1, c1), d2 = __hiloint2double((int)h2, c2), d3 = __hiloint2double((int)h3, c3);
     order_keys(d0, d1); order_keys(d2, d3); order_keys(d0, d2); order_keys(d1, d3); order_keys(d1, d2);
     const uint32_t s0h = (uint32_t)__double2hiint(d0), s1h = (uint32_t)__double2hiint(d1), s2h = (uint32_t)__double2hiint(d2), s3h = (uint32_t)__double2hiint(d3);
     const int32_t r0 = __double2loint(d0), r1 = __double2loint(d1), r2 = __double2loint(d2), r3 = __double2loint(d3);
+#endif
     if ((st.top - 1) + 2 + (int)levels <= budget) {
         // unconditional stores, conditional advance: three ds_write_b32 without a branch each (entries top .. top + 2 exist: the
         // rule above leaves room for them; a slot written for a child that was not hit is simply overwritten by the next push)

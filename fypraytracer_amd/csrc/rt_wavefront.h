@@ -110,8 +110,12 @@ RT_DEV uint32_t spatial_reuse_speculative(const DevCamera& cam, const DevFrame& 
 // fetched from memory.  Measured (tuning key 14 = 2) and NOT the default: see the numbers in profiles/README.md r02 — the tile samples
 // 5 x 256 of its 5776 window entries, so staging moves 4.5x the bytes the gathers touch, and 69 KB of LDS leave two workgroups per CU.
 constexpr int kWinMax = 16 + 2 * 30;
+// (MODE 0 compiles to 74 VGPRs = 6 waves per SIMD; capped to the 72 of 7 waves it spills two registers to scratch — r03, tools/kernel_resources.py -DRT_SETUP_WAVES=...)
+#ifndef RT_SETUP_WAVES
+#define RT_SETUP_WAVES
+#endif
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
+__global__ __launch_bounds__(kBlock) RT_SETUP_WAVES void k_di_part2_setup(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, ShadowQueue q) {
     constexpr bool SPECULATIVE = MODE == 1;
     uint32_t x, y;
     const bool inside = pixel_of_thread(fr, fr.rowBegin, fr.rowEnd, x, y);

@@ -157,7 +157,7 @@ struct ProductTracer : Tracer {
         const float cut = tL * 1.000001f;
         int32_t stack[128]; int top = 0; int32_t cur = rootRef;
         Payload r = Miss(); r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
-        ev(0xF1);
+        ev(0xF1); ev((uint8_t)(lightTri & 0xFFu)); ev((uint8_t)((lightTri >> 8) & 0xFFu)); ev((uint8_t)((lightTri >> 16) & 0xFFu));   // + the light triangle (3 bytes, < 0xF0 each is not required: the reader skips them by position)
         while (true) {
             if (cur >= 0) {
                 ev(0x01);

@@ -140,7 +140,7 @@ struct ConeBounds { vec3 axis{0, 0, 0}; float theta_o = 0.0f, theta_e = 0.0f; };
 
 // glm::rotate(mat4(1), angle, axis) applied to (v, 0)   (ConeBounds.cuh:40-43); host-only, libm trig.
 static inline vec3 RotateAbout(vec3 v, float angle, vec3 axisIn) {
-    const float c = cosf(angle), s = sinf(angle);
+    const float c = t_cos(angle), s = t_sin(angle);
     vec3 axis = normalize(axisIn);
     vec3 temp = axis * (1.0f - c);
     // glm::rotate builds Rotate[col][row]; Result = m * Rotate with m = identity
@@ -153,7 +153,7 @@ static inline vec3 RotateAbout(vec3 v, float angle, vec3 axisIn) {
 }
 static inline ConeBounds UnionCone(ConeBounds a, ConeBounds b) {                       // ConeBounds.cuh:14-45
     if (b.theta_o > a.theta_o) std::swap(a, b);
-    float theta_d = acosf(dot(a.axis, b.axis));
+    float theta_d = t_acos(dot(a.axis, b.axis));
     float theta_e = fmaxf(a.theta_e, b.theta_e);
     if (fminf(theta_d + b.theta_o, kPi) <= a.theta_o) return {a.axis, a.theta_o, theta_e};
     float theta_o = (a.theta_o + theta_d + b.theta_o) * 0.5f;
@@ -173,8 +173,8 @@ struct LightTree { std::vector<LTNode> nodes; uint32_t rootIndex = ~0u; };
 static inline float OrientMeasure(float theta_o, float theta_e) {                      // LightTree.cpp:318-329
     const float piHalf = 0.5f * kPi;
     float theta_w = fminf(theta_o + theta_e, kPi);
-    float a = (2 * kPi) * (1 - cosf(theta_o));
-    float b = piHalf * (2 * theta_w * sinf(theta_o) - cosf(theta_o - 2 * theta_w) - (2 * theta_o * sinf(theta_o)) + cosf(theta_o));
+    float a = (2 * kPi) * (1 - t_cos(theta_o));
+    float b = piHalf * (2 * theta_w * t_sin(theta_o) - t_cos(theta_o - 2 * theta_w) - (2 * theta_o * t_sin(theta_o)) + t_cos(theta_o));
     return a + b;
 }
 

@@ -49,169 +49,160 @@ def record(W, H):
     orc.lib.orc_take_events(orc.h, buf.ctypes.data, n)
     orc.lib.orc_record_events(orc.h, 0)
     print(f"# recorded {n} event bytes in {time.time() - t:.1f} s", file=sys.stderr)
-    return buf
+    # which pixels carry a shadow ray: the primary ray hit a surface that does not emit (the k-th shadow ray of the log is the k-th of them, row-major)
+    pay = orc.read_buffer(capi.BUF_PAYLOAD)
+    emits = np.array([m.emission_power * max(m.emission_color) > 0 for m in sc.materials])
+    obj = pay["objectIndex"]
+    live = (pay["hitDistance"] >= 0) & ~emits[sc.triangles["materialIndex"][np.maximum(obj, 0)]]
+    return buf, np.flatnonzero(live).astype(np.int64)
 
 
 def split_rays(buf):
     """-> list of (kind, events) with events = list of ints: 0 = node visit, k > 0 = leaf with k triangle tests (k may be 0: light-only leaf)"""
     rays = []
-    starts = np.flatnonzero((buf >= 0xF0) & (buf != 0xFF))
-    ends = np.flatnonzero(buf == 0xFF)
-    # nested fall-back rays (a shadow ray that misses its light runs a closest-hit ray) do not occur inside another ray's record: the
-    # fall-back is decided before the shadow record starts
-    assert len(starts) == len(ends)
-    for s, e in zip(starts, ends):
-        kind = int(buf[s]) & 0xF
-        ev = buf[s + 1:e]
+    k, n = 0, len(buf)
+    while k < n:                                             # sequential parse: a shadow ray's header carries 3 bytes of light-triangle id
+        assert 0xF0 <= buf[k] < 0xFF, (k, buf[k])
+        kind = int(buf[k]) & 0xF
+        k += 1
+        light = -1
+        if kind == 1:
+            light = int(buf[k]) | (int(buf[k + 1]) << 8) | (int(buf[k + 2]) << 16)
+            k += 3
+        e = k
+        while buf[e] != 0xFF:
+            e += 1
+        ev = buf[k:e]
         seq = np.where(ev == 1, 0, (ev & 0xF).astype(np.int16) + np.where(ev >= 0x10, 100, 0)).astype(np.int16)   # leaf with k tests -> 100 + k
-        rays.append((kind, seq))
+        rays.append((kind, seq, light))
+        k = e + 1
     return rays
 
 
 class Wave:
-    """64 lanes, each with an optional ray = (event sequence, position, triangles left in the current leaf)"""
+    """64 lanes x `slots` rays per lane; a ray = a row of the padded event matrix E (0 node visit, 100 + k leaf with k triangle tests, -1 end)"""
 
-    def __init__(self, tasks, slots=1):
-        self.tasks = tasks                  # list of event arrays, consumed from the front
-        self.next = 0
-        self.slots = slots
-        self.seq = [[None] * slots for _ in range(64)]
+    def __init__(self, E, first, count, slots=1):
+        self.E, self.next, self.end, self.slots = E, first, first + count, slots
+        self.task = np.full((64, slots), -1, dtype=np.int64)
         self.pos = np.zeros((64, slots), dtype=np.int64)
-        self.tri = np.zeros((64, slots), dtype=np.int64)       # > 0: in a leaf with this many triangle rounds left
-        self.active = np.zeros((64, slots), dtype=bool)
+        self.tri = np.zeros((64, slots), dtype=np.int64)
         self.cycles = 0
         self.lane_cycles = 0                # cycles x lanes that took part
 
-    def state(self, l, s):
-        """'n' node visit wanted, 't' triangle round wanted, None finished"""
-        if not self.active[l, s]:
-            return None
-        if self.tri[l, s] > 0:
-            return 't'
-        q = self.seq[l][s]
-        if self.pos[l, s] >= len(q):
-            return None
-        return 'n' if q[self.pos[l, s]] == 0 else 't'
+    def cur(self):
+        e = self.E[np.maximum(self.task, 0), self.pos]
+        return np.where(self.task >= 0, e, -1)
+
+    def settle(self):
+        """enter leaves (a leaf's triangle count becomes pending triangle rounds), retire finished rays"""
+        while True:
+            e = self.cur()
+            at = (self.task >= 0) & (self.tri == 0) & (e >= 100)
+            if not at.any():
+                break
+            self.tri = np.where(at, e - 100, self.tri)
+            self.pos = np.where(at, self.pos + 1, self.pos)
+        e = self.cur()
+        done = (self.task >= 0) & (self.tri == 0) & (e < 0)
+        self.task = np.where(done, -1, self.task)
 
     def want(self):
-        n = np.zeros((64, self.slots), dtype=bool); t = np.zeros((64, self.slots), dtype=bool)
-        for l in range(64):
-            for s in range(self.slots):
-                st = self.state(l, s)
-                if st == 'n':
-                    n[l, s] = True
-                elif st == 't':
-                    t[l, s] = True
-        return n, t
+        e = self.cur()
+        act = self.task >= 0
+        return act & (self.tri == 0) & (e == 0), act & (self.tri > 0)
 
-    def retire(self):
-        for l in range(64):
-            for s in range(self.slots):
-                if self.active[l, s] and self.tri[l, s] == 0 and self.pos[l, s] >= len(self.seq[l][s]):
-                    self.active[l, s] = False
+    @staticmethod
+    def first_slot(m):
+        """per lane only the first wanting slot takes part in a round"""
+        out = np.zeros_like(m)
+        taken = np.zeros(m.shape[0], dtype=bool)
+        for s in range(m.shape[1]):
+            out[:, s] = m[:, s] & ~taken
+            taken |= m[:, s]
+        return out
 
     def node_round(self, n):
-        """one node visit for one ray of every lane that has a ray in node state (slot 0 first)"""
-        took = 0
-        for l in range(64):
-            for s in range(self.slots):
-                if n[l, s]:
-                    self.pos[l, s] += 1
-                    took += 1
-                    break
-        self.cycles += C_NODE; self.lane_cycles += C_NODE * took
-
-    def enter_leaves(self):
-        for l in range(64):
-            for s in range(self.slots):
-                if self.active[l, s] and self.tri[l, s] == 0 and self.pos[l, s] < len(self.seq[l][s]):
-                    e = self.seq[l][s][self.pos[l, s]]
-                    if e >= 100:
-                        self.tri[l, s] = e - 100
-                        self.pos[l, s] += 1
+        n = self.first_slot(n)
+        self.pos = np.where(n, self.pos + 1, self.pos)
+        self.cycles += C_NODE; self.lane_cycles += C_NODE * int(n.sum())
 
     def tri_round(self, t):
-        took = 0
-        for l in range(64):
-            for s in range(self.slots):
-                if t[l, s] and self.tri[l, s] > 0:
-                    self.tri[l, s] -= 1
-                    took += 1
-                    break
-        self.cycles += C_TRI; self.lane_cycles += C_TRI * took
+        t = self.first_slot(t)
+        self.tri = np.where(t, self.tri - 1, self.tri)
+        self.cycles += C_TRI; self.lane_cycles += C_TRI * int(t.sum())
+
+    def idle_slots(self):
+        return int((self.task < 0).sum())
 
     def refill(self):
-        got = 0
-        for l in range(64):
-            for s in range(self.slots):
-                if not self.active[l, s] and self.next < len(self.tasks):
-                    self.seq[l][s] = self.tasks[self.next]; self.next += 1
-                    self.pos[l, s] = 0; self.tri[l, s] = 0; self.active[l, s] = True
-                    got += 1
+        free = np.argwhere(self.task < 0)
+        got = min(len(free), self.end - self.next)
+        for k in range(got):
+            l, sl = free[k]
+            self.task[l, sl] = self.next + k; self.pos[l, sl] = 0; self.tri[l, sl] = 0
+        self.next += got
         self.cycles += C_REFILL; self.lane_cycles += C_REFILL * min(64, got)
 
 
-def run_kernel_policy(tasks, quorum=24, refill_lanes=24, slots=1, greedy=False, tri_weight=None):
+def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, greedy=False, tri_weight=1.0, select_cost=0, select_cost_tri=None):
     """the persistent kernel's loop (rt_wavefront.h) on one wave; greedy: every round is the kind with the larger (lanes / cost)"""
-    w = Wave(tasks, slots)
-    more = True
+    w = Wave(E, first, count, slots)
     while True:
-        idle = 64 * slots - int(w.active.sum())
-        more = w.next < len(w.tasks)
-        if (more and idle >= refill_lanes * slots) or (not w.active.any() and more):
+        more = w.next < w.end
+        if more and (w.idle_slots() >= refill_lanes * slots or not (w.task >= 0).any()):
             w.refill()
-        if not w.active.any():
-            if w.next >= len(w.tasks):
+        w.settle()
+        if not (w.task >= 0).any():
+            if w.next >= w.end:
                 break
             continue
         while True:
-            w.enter_leaves()
+            w.settle()
             n, t = w.want()
             ln, lt = int(n.any(axis=1).sum()), int(t.any(axis=1).sum())
             if greedy:
-                if ln == 0 and lt == 0:
-                    pass
-                elif lt * C_NODE * (tri_weight or 1.0) > ln * C_TRI:
-                    w.tri_round(t)
-                else:
-                    w.node_round(n)
+                if lt * C_NODE * tri_weight > ln * C_TRI:
+                    w.tri_round(t); w.cycles += select_cost if select_cost_tri is None else select_cost_tri
+                elif ln:
+                    w.node_round(n); w.cycles += select_cost
             else:
                 while ln >= 1:                                   # node loop: until fewer than `quorum` lanes are still in it
                     w.node_round(n)
-                    w.enter_leaves()
+                    w.settle()
                     n, t = w.want()
                     ln = int(n.any(axis=1).sum())
                     if ln < quorum:
                         break
-                n, t = w.want()
                 if t.any():
                     w.cycles += C_LEAF_PHASE
-                    while True:                                  # leaf phase: every lane at a leaf tests all its triangles
-                        n2, t = w.want()
-                        if not t.any():
-                            break
+                    while t.any():                               # leaf phase: every lane at a leaf tests all its triangles
                         w.tri_round(t)
-            w.retire()
-            act = int(w.active.any(axis=1).sum())
-            if act == 0:
+                        n, t = w.want()
+            w.settle()
+            if not (w.task >= 0).any():
                 break
-            more = w.next < len(w.tasks)
-            if more and (64 * slots - int(w.active.sum())) >= refill_lanes * slots:
+            if w.next < w.end and w.idle_slots() >= refill_lanes * slots:
                 break
     return w.cycles, w.lane_cycles
 
 
 def main():
     W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 144)
-    cache = Path(f"/tmp/wave_sim_events_{W}x{H}.npy")
+    cache = Path(f"/tmp/wave_sim_events2_{W}x{H}.npz")
     if cache.exists():
-        buf = np.load(cache)
+        z = np.load(cache); buf, live_px = z["buf"], z["live"]
     else:
-        buf = record(W, H)
-        np.save(cache, buf)
+        buf, live_px = record(W, H)
+        np.savez(cache, buf=buf, live=live_px)
     rays = split_rays(buf)
-    shadow = [q for k, q in rays if k == 1]
-    primary = [q for k, q in rays if k == 0]
+    shadow = [q for k, q, l in rays if k == 1]
+    lights = np.array([l for k, q, l in rays if k == 1])
+    primary = [q for k, q, l in rays if k == 0]
+    # a shadow ray whose light test failed runs as a closest-hit ray (kind 0) instead: drop those pixels from the map (rare)
+    if len(live_px) != len(shadow):
+        print(f"# {len(live_px)} live pixels, {len(shadow)} shadow rays: pixel map unavailable", file=sys.stderr)
+        live_px = None
     nv = np.mean([int((q == 0).sum()) for q in shadow]); tt = np.mean([int((q[q >= 100] - 100).sum()) for q in shadow])
     print(json.dumps({"rays_primary": len(primary), "rays_shadow": len(shadow), "shadow_node_visits_per_ray": round(float(nv), 2), "shadow_tri_tests_per_ray": round(float(tt), 2),
                       "ideal_cycles_per_ray_at_full_utilisation": round((nv * C_NODE + tt * C_TRI) / 64, 1)}))
@@ -222,14 +213,44 @@ def main():
                 ("kernel q24 r16", dict(quorum=24, refill_lanes=16)), ("kernel q24 r8", dict(quorum=24, refill_lanes=8)),
                 ("greedy r24", dict(greedy=True, refill_lanes=24)), ("greedy r16", dict(greedy=True, refill_lanes=16)), ("greedy r8", dict(greedy=True, refill_lanes=8)),
                 ("greedy r24 tri x1.5", dict(greedy=True, refill_lanes=24, tri_weight=1.5)),
-                ("two rays per lane, kernel q24 r24", dict(quorum=24, refill_lanes=24, slots=2)), ("two rays per lane, greedy r16", dict(greedy=True, refill_lanes=16, slots=2))]
+                ("two rays per lane, kernel q24 r24", dict(quorum=24, refill_lanes=24, slots=2)), ("two rays per lane, greedy r16", dict(greedy=True, refill_lanes=16, slots=2)),
+                ("two rays per lane, greedy r8", dict(greedy=True, refill_lanes=8, slots=2)), ("two rays per lane, greedy r24", dict(greedy=True, refill_lanes=24, slots=2)),
+                ("two rays per lane, greedy r16, +60 cycles per round for the slot select", dict(greedy=True, refill_lanes=16, slots=2, select_cost=60)),
+                ("two rays per lane, greedy r16, slot select +57 per node round, +100 per triangle round", dict(greedy=True, refill_lanes=16, slots=2, select_cost=57, select_cost_tri=100)),
+                ("two rays per lane, greedy r16, +57 / +100, triangle rounds weighted x0.7", dict(greedy=True, refill_lanes=16, slots=2, select_cost=57, select_cost_tri=100, tri_weight=0.7)),
+                ("three rays per lane, greedy r16", dict(greedy=True, refill_lanes=16, slots=3)), ("four rays per lane, greedy r16", dict(greedy=True, refill_lanes=16, slots=4))]
     nwaves = 24
     per = (len(shadow) // nwaves // chunk) * chunk
+    L = max(len(q) for q in shadow) + 1
+
+    def matrix(order):
+        E = np.full((len(shadow), L), -1, dtype=np.int16)
+        for k, src in enumerate(order):
+            q = shadow[src]
+            E[k, :len(q)] = q
+        return E
+    orders = {"row-major": np.arange(len(shadow))}
+    if live_px is not None:
+        x, y = live_px % W, live_px // W
+        tile16 = (y // 16) * ((W + 15) // 16) + (x // 16)
+        wave8 = ((y % 16) // 8) * 2 + ((x % 16) // 8)
+        lane = (y % 8) * 8 + (x % 8)
+        orders["tiles (the setup kernel's order: 16x16 workgroups, 8x8 waves)"] = np.lexsort((lane, wave8, tile16))
+        orders["tiles, tasks of a 16x16 tile sorted by light"] = np.lexsort((lane, lights, tile16))
+        orders["tiles, sorted by light inside 32x32"] = np.lexsort((lane, lights, (y // 32) * ((W + 31) // 32) + (x // 32)))
+    for oname, order in orders.items():
+        E = matrix(order)
+        c = l = 0
+        for wv in range(nwaves):
+            cc, ll = run_kernel_policy(E, wv * per, per, quorum=24, refill_lanes=24)
+            c += cc; l += ll
+        print(json.dumps({"queue_order": oname, "policy": "kernel q24 r24", "issue_cycles_per_ray": round(c / (nwaves * per), 1), "lane_utilisation": round(l / (c * 64), 3)}), flush=True)
+    E = matrix(orders.get("tiles (the setup kernel's order: 16x16 workgroups, 8x8 waves)", orders["row-major"]))
     for name, kw in policies:
         t0 = time.time()
         cyc = lane = 0
         for wv in range(nwaves):
-            c, l = run_kernel_policy(shadow[wv * per:(wv + 1) * per], **kw)
+            c, l = run_kernel_policy(E, wv * per, per, **kw)
             cyc += c; lane += l
         nr = nwaves * per
         print(json.dumps({"policy": name, "issue_cycles_per_ray": round(cyc / nr, 1), "lane_utilisation": round(lane / (cyc * 64), 3), "rays": nr, "sim_s": round(time.time() - t0, 1)}), flush=True)
