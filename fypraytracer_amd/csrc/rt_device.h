@@ -164,8 +164,11 @@ constexpr int kStackBudget = kStackDepth - 1;   // one entry is the exit sentine
 // instantiated without it and carry neither the counters nor their instructions.
 template <bool COUNT>
 RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const RayPk& r, float cut, Stack& st, uint32_t& nBox, uint32_t& nNode) {
-    const bool resumed = cur >= kResumeBase;
-    const int32_t node = resumed ? ((cur - kResumeBase) >> 4) : cur;
+    // resume entries are rare: one wave-uniform test keeps their decoding (and, below, their slot masks) off the common path — the kernels
+    // are bound by instruction issue, every instruction and every exec-mask region of a visit is paid on each of ~18 visits per ray
+    const bool anyResumed = __ballot(cur >= kResumeBase) != 0ull;
+    int32_t node = cur; uint32_t allow = 0xFu;
+    if (anyResumed) { const bool resumed = cur >= kResumeBase; node = resumed ? ((cur - kResumeBase) >> 4) : cur; allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu; }
     float4 q0, q1, q2; float2 q3;
 #ifdef RT_TOPCACHE
     if ((uint32_t)node < st.topCount) {
@@ -178,7 +181,7 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
         q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
     }
     const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u, levels = ex >> 27;
-    if (COUNT) { nBox += (uint32_t)__popc((resumed ? ((uint32_t)cur & 0xFu) : 0xFu) & ((1u << cnt) - 1u)); nNode += 1u; }
+    if (COUNT) { nBox += (uint32_t)__popc(allow & ((1u << cnt) - 1u)); nNode += 1u; }
     const float Ax = __int_as_float((int)((ex & 0xFFu) << 23)) * r.ix, Ay = __int_as_float((int)(((ex >> 8) & 0xFFu) << 23)) * r.iy,
                 Az = __int_as_float((int)(((ex >> 16) & 0xFFu) << 23)) * r.iz;
     const float Bx = (q0.x - r.ox) * r.ix, By = (q0.y - r.oy) * r.iy, Bz = (q0.z - r.oz) * r.iz;
@@ -210,8 +213,7 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     uint32_t h1 = (k1 <= f1) ? __float_as_uint(k1) : kMissHi;
     uint32_t h2 = (k2 <= f2) ? __float_as_uint(k2) : kMissHi;
     uint32_t h3 = (k3 <= f3_) ? __float_as_uint(k3) : kMissHi;
-    if (__ballot(resumed) != 0ull) {                                  // rare: a resumed visit only looks at the slots still owed
-        const uint32_t allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu;
+    if (anyResumed) {                                                 // rare: a resumed visit only looks at the slots still owed
         h0 = (allow & 1u) ? h0 : kMissHi; h1 = (allow & 2u) ? h1 : kMissHi; h2 = (allow & 4u) ? h2 : kMissHi; h3 = (allow & 8u) ? h3 : kMissHi;
     }
     const int32_t c0 = __float_as_int(q1.x), c1 = __float_as_int(q1.y), c2 = __float_as_int(q1.z), c3 = __float_as_int(q1.w);
@@ -225,17 +227,20 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     const uint32_t s0h = (uint32_t)__double2hiint(d0), s1h = (uint32_t)__double2hiint(d1), s2h = (uint32_t)__double2hiint(d2), s3h = (uint32_t)__double2hiint(d3);
     const int32_t r0 = __double2loint(d0), r1 = __double2loint(d1), r2 = __double2loint(d2), r3 = __double2loint(d3);
 #endif
-    if ((st.top - 1) + 2 + (int)levels <= budget) {
-        // unconditional stores, conditional advance: three ds_write_b32 without a branch each (entries top .. top + 2 exist: the
-        // rule above leaves room for them; a slot written for a child that was not hit is simply overwritten by the next push)
-        st.lds[st.top * kBlock] = r3; st.top += (s3h < kMissHi) ? 1 : 0;
-        st.lds[st.top * kBlock] = r2; st.top += (s2h < kMissHi) ? 1 : 0;
-        st.lds[st.top * kBlock] = r1; st.top += (s1h < kMissHi) ? 1 : 0;
-    } else if (s1h < kMissHi) {                                      // two or more hits and no room to push them one by one
+    // unconditional stores, conditional advance: three ds_write_b32 without a branch each (entries top .. top + 2 exist: the
+    // rule above leaves room for them; a slot written for a child that was not hit is simply overwritten by the next push)
+#define RT_PUSH3() do { st.lds[st.top * kBlock] = r3; st.top += (s3h < kMissHi) ? 1 : 0; \
+                        st.lds[st.top * kBlock] = r2; st.top += (s2h < kMissHi) ? 1 : 0; \
+                        st.lds[st.top * kBlock] = r1; st.top += (s1h < kMissHi) ? 1 : 0; } while (0)
+    const bool room = (st.top - 1) + 2 + (int)levels <= budget;
+    if (__ballot(!room) == 0ull) RT_PUSH3();                          // the common case, wave-uniform: no exec-mask region around the pushes
+    else if (room) RT_PUSH3();
+    else if (s1h < kMissHi) {                                         // two or more hits and no room to push them one by one
         const uint32_t hit = (h0 < kMissHi ? 1u : 0u) | (h1 < kMissHi ? 2u : 0u) | (h2 < kMissHi ? 4u : 0u) | (h3 < kMissHi ? 8u : 0u);
         const uint32_t nearest = (c0 == r0) ? 1u : (c1 == r0) ? 2u : (c2 == r0) ? 4u : 8u;     // the nearest child's slot (references of hit slots are distinct)
         st.push(kResumeBase + (int32_t)(((uint32_t)node << 4) | (hit & ~nearest)));
     }
+#undef RT_PUSH3
     return (s0h < kMissHi) ? r0 : st.pop();
 }
 

@@ -170,6 +170,7 @@ public:
     const mat4& GetPrevView() const { return m_PrevView; }
     const mat4& GetInverseView() const { return m_InverseView; }
     vec3& GetPosition() { return m_Position; }
+    vec3& GetForwardDirection() { return m_Forward; }                      // (Camera.h: GetDirection; assigned without a view update by scenes that set the pose in two steps)
     uint32_t GetViewportWidth() const { return m_W; }
     uint32_t GetViewportHeight() const { return m_H; }
     // Camera::OnUpdate (Camera.cpp:18-94) with the right mouse button held; Walnut::Input is replaced by its values: `keys` = the

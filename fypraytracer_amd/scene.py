@@ -7,13 +7,20 @@ kernels read: `Material` (Material.cuh:7-21), `Scene.add_new_mesh_to_scene`
 (Camera.cpp:96-153: projection / view / inverses; the per-pixel ray directions are
 generated on the GPU from the inverse matrices).  Matrices are numpy float32 arrays
 indexed [column][row] (glm::mat4 memory order), so `.reshape(16)` is what crosses the
-C ABI.  glm itself is an un-vendored dependency of the reference; the
-formulas below are glm's documented right-handed, [-1,1]-depth definitions.
+C ABI.
+
+ONE implementation of the arithmetic: the transform of a mesh, the vertex loop, the emissive test and the
+whole Camera are host/HostTypes.h (what the C++ facade uses), called here through libfyprt_host.so — this
+module holds containers and bookkeeping only (the round-2 numpy copy agreed with the C++
+one on the transforms but not, to the last bit, on the camera matrices).  glm itself is an un-vendored
+dependency of the reference; HostTypes.h states glm's documented right-handed,
+[-1,1]-depth definitions.
 """
 from __future__ import annotations
 
-import math
+import ctypes as C
 from dataclasses import dataclass, field
+from pathlib import Path
 
 import numpy as np
 
@@ -36,177 +43,132 @@ class Material:  # Material.cuh:7-16 (defaults included)
         return np.asarray(self.emission_color, dtype=F) * F(self.emission_power)
 
 
-def _mat_identity():
-    return np.eye(4, dtype=F)
+_HOST_PATH = Path(__file__).resolve().parent / "host" / "libfyprt_host.so"
+_host = None
 
 
-def _matmul(a, b):
-    """Product of two [col][row] matrices: (a*b)[col] = sum_k a[k] * b[col][k]."""
-    out = np.zeros((4, 4), dtype=F)
-    for j in range(4):
-        acc = np.zeros(4, dtype=F)
-        for k in range(4):
-            acc = acc + a[k] * b[j][k]
-        out[j] = acc
+def _host_lib():
+    """libfyprt_host.so (host/build.sh): fails loudly when it is not built."""
+    global _host
+    if _host is None:
+        if not _HOST_PATH.exists():
+            raise RuntimeError(f"{_HOST_PATH} is missing: run `python __graft_entry__.py build` (host/build.sh)")
+        L = C.CDLL(str(_HOST_PATH))
+        vp, fp = C.c_void_p, C.c_void_p
+        L.fyprt_host_mesh_matrix.argtypes = [fp, fp, fp, fp]
+        L.fyprt_host_to_world.argtypes = [fp, fp, fp, C.c_uint32]
+        L.fyprt_host_is_emissive.argtypes = [fp, C.c_float]
+        L.fyprt_host_camera_create.restype = vp
+        L.fyprt_host_camera_create.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.fyprt_host_camera_destroy.argtypes = [vp]
+        L.fyprt_host_camera_on_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
+        for f in ("set_position", "set_direction", "assign_forward", "assign_position", "state"):
+            getattr(L, "fyprt_host_camera_" + f).argtypes = [vp, fp]
+        L.fyprt_host_camera_on_update.argtypes = [vp, C.c_float, C.c_char_p, C.c_float, C.c_float]
+        L.fyprt_host_camera_commit_frame.argtypes = [vp]
+        _host = L
+    return _host
+
+
+def _f3(v):
+    return np.ascontiguousarray(np.asarray(v, dtype=F).reshape(3))
+
+
+def mesh_matrix(pos, rotation, scale_):
+    """Mesh::UpdateWorldTransform: T * yawPitchRoll(radians(ry), radians(rx), radians(rz)) * S as a [col][row] float32 matrix."""
+    out = np.zeros(16, dtype=F)
+    p, r, sc = _f3(pos), _f3(rotation), _f3(scale_)
+    _host_lib().fyprt_host_mesh_matrix(p.ctypes.data, r.ctypes.data, sc.ctypes.data, out.ctypes.data)
+    return out.reshape(4, 4)
+
+
+def to_world(matrix, vertices):
+    """The vertex loop of Scene::AddNewMeshToScene / SceneManager (Scene.cpp:42-51, SceneManager.cpp:30-41) on VERTEX_DTYPE records."""
+    m = np.ascontiguousarray(np.asarray(matrix, dtype=F).reshape(16))
+    vin = np.ascontiguousarray(vertices)
+    out = np.empty_like(vin)
+    if len(vin):
+        _host_lib().fyprt_host_to_world(m.ctypes.data, vin.ctypes.data, out.ctypes.data, len(vin))
     return out
 
 
-def translate(v):  # glm::translate(mat4(1), v)
-    m = _mat_identity()
-    m[3, :3] = np.asarray(v, dtype=F)
-    return m
-
-
-def scale(v):  # glm::scale(mat4(1), v)
-    m = _mat_identity()
-    m[0, 0], m[1, 1], m[2, 2] = [F(x) for x in v]
-    return m
-
-
-def yaw_pitch_roll(yaw, pitch, roll):  # glm::yawPitchRoll (gtx/euler_angles)
-    ch, sh = math.cos(yaw), math.sin(yaw)
-    cp, sp = math.cos(pitch), math.sin(pitch)
-    cb, sb = math.cos(roll), math.sin(roll)
-    m = _mat_identity()
-    m[0, 0] = ch * cb + sh * sp * sb
-    m[0, 1] = sb * cp
-    m[0, 2] = -sh * cb + ch * sp * sb
-    m[1, 0] = -ch * sb + sh * sp * cb
-    m[1, 1] = cb * cp
-    m[1, 2] = sb * sh + ch * sp * cb
-    m[2, 0] = sh * cp
-    m[2, 1] = -sp
-    m[2, 2] = ch * cp
-    return m.astype(F)
-
-
-def perspective_fov(fov, width, height, z_near, z_far):  # glm::perspectiveFov (RH, NO)
-    h = math.cos(0.5 * fov) / math.sin(0.5 * fov)
-    w = h * height / width
-    m = np.zeros((4, 4), dtype=F)
-    m[0, 0] = w
-    m[1, 1] = h
-    m[2, 2] = -(z_far + z_near) / (z_far - z_near)
-    m[2, 3] = -1.0
-    m[3, 2] = -(2.0 * z_far * z_near) / (z_far - z_near)
-    return m
-
-
-def look_at(eye, center, up):  # glm::lookAt (RH)
-    eye, center, up = (np.asarray(a, dtype=np.float64) for a in (eye, center, up))
-    f = center - eye
-    f /= np.linalg.norm(f)
-    s = np.cross(f, up)
-    s /= np.linalg.norm(s)
-    u = np.cross(s, f)
-    m = _mat_identity().astype(np.float64)
-    m[0, 0], m[1, 0], m[2, 0] = s
-    m[0, 1], m[1, 1], m[2, 1] = u
-    m[0, 2], m[1, 2], m[2, 2] = -f
-    m[3, 0], m[3, 1], m[3, 2] = -np.dot(s, eye), -np.dot(u, eye), np.dot(f, eye)
-    return m.astype(F)
-
-
-def inverse(m):
-    # [col][row] storage == transpose of the mathematical matrix
-    return np.linalg.inv(m.astype(np.float64).T).T.astype(F)
-
-
-# glm quaternion helpers used by Camera::OnUpdate (gtc/quaternion: angleAxis, cross == Hamilton product, normalize, rotate)
-def _quat_angle_axis(angle, axis):
-    h = F(angle) * F(0.5)
-    s = F(math.sin(h))
-    return np.array([math.cos(h), axis[0] * s, axis[1] * s, axis[2] * s], dtype=F)      # (w, x, y, z)
-
-
-def _quat_mul(a, b):
-    w1, x1, y1, z1 = a
-    w2, x2, y2, z2 = b
-    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
-                     w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2, w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2], dtype=F)
-
-
-def _quat_normalize(q):
-    n = F(math.sqrt(float(np.dot(q, q))))
-    return (q / n).astype(F) if n > 0 else np.array([1, 0, 0, 0], dtype=F)
-
-
-def _quat_rotate(q, v):
-    qv = q[1:4]
-    uv = np.cross(qv, v).astype(F)
-    uuv = np.cross(qv, uv).astype(F)
-    return (v + ((uv * q[0]) + uuv) * F(2.0)).astype(F)
-
-
 class Camera:
-    """Camera.h:9-83 / Camera.cpp.  `on_resize`, `set_position`, `set_direction` keep the
-    reference's semantics, including the reset of the previous-frame matrices on an explicit
-    pose change (Camera.cpp:108-116) and `commit_frame()` = WalnutApp.cpp:908-909."""
+    """Camera.h:9-83 / Camera.cpp — a handle to host/HostTypes.h's Camera.  `on_resize`, `set_position`, `set_direction` keep the
+    reference's semantics, including the reset of the previous-frame matrices on an explicit pose change (Camera.cpp:108-116) and
+    `commit_frame()` = WalnutApp.cpp:908-909.  The matrices are read back after every call as [col][row] float32 arrays."""
+
+    _NAMES = ("projection", "view", "prev_projection", "prev_view", "inverse_projection", "inverse_view")
 
     def __init__(self, vertical_fov=45.0, near_clip=0.1, far_clip=100.0):
         self.vertical_fov, self.near_clip, self.far_clip = vertical_fov, near_clip, far_clip
-        self.position = np.array([0, 0, 6], dtype=F)          # Camera.cpp:15-16
-        self.forward = np.array([0, 0, -1], dtype=F)
+        self._lib = _host_lib()
+        self._h = C.c_void_p(self._lib.fyprt_host_camera_create(vertical_fov, near_clip, far_clip))
         self.width = self.height = 0
-        self.projection = self.view = self.prev_projection = self.prev_view = _mat_identity()
-        self.inverse_projection = self.inverse_view = _mat_identity()
+        self._pull()
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.fyprt_host_camera_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _pull(self):
+        st = np.zeros(102, dtype=F)
+        self._lib.fyprt_host_camera_state(self._h, st.ctypes.data)
+        for k, n in enumerate(self._NAMES):
+            setattr(self, n, st[16 * k:16 * k + 16].reshape(4, 4).copy())
+        self._position, self._forward = st[96:99].copy(), st[99:102].copy()
+
+    # Camera::GetPosition / GetDirection return references the caller may assign through: plain member writes, no view update
+    @property
+    def position(self):
+        return self._position
+
+    @position.setter
+    def position(self, p):
+        p = _f3(p)
+        self._lib.fyprt_host_camera_assign_position(self._h, p.ctypes.data)
+        self._position = p.copy()
+
+    @property
+    def forward(self):
+        return self._forward
+
+    @forward.setter
+    def forward(self, d):
+        d = _f3(d)
+        self._lib.fyprt_host_camera_assign_forward(self._h, d.ctypes.data)
+        self._forward = d.copy()
 
     def on_resize(self, width, height):  # Camera.cpp:96-106
-        if width == self.width and height == self.height:
-            return
+        self._lib.fyprt_host_camera_on_resize(self._h, width, height)
         self.width, self.height = width, height
-        self.projection = perspective_fov(math.radians(self.vertical_fov), float(width), float(height), self.near_clip, self.far_clip)
-        self.inverse_projection = inverse(self.projection)
-
-    def _update_view(self):  # Camera.cpp:108-134
-        self.view = look_at(self.position, self.position + self.forward, (0, 1, 0))
-        self.inverse_view = inverse(self.view)
-        self.prev_projection, self.prev_view = self.projection.copy(), self.view.copy()
+        self._pull()
 
     def set_position(self, p):
-        self.position = np.asarray(p, dtype=F)
-        self._update_view()
+        p = _f3(p)
+        self._lib.fyprt_host_camera_set_position(self._h, p.ctypes.data)
+        self._pull()
 
     def set_direction(self, d):
-        self.forward = np.asarray(d, dtype=F)
-        self._update_view()
+        d = _f3(d)
+        self._lib.fyprt_host_camera_set_direction(self._h, d.ctypes.data)
+        self._pull()
 
     def commit_frame(self):
         """MainLayer::Render tail (WalnutApp.cpp:908-909): prev := current."""
-        self.prev_projection, self.prev_view = self.projection.copy(), self.view.copy()
+        self._lib.fyprt_host_camera_commit_frame(self._h)
+        self._pull()
 
     def on_update(self, ts, keys="", mouse_delta=(0.0, 0.0)):
         """Camera::OnUpdate (Camera.cpp:18-94) with the right mouse button held: `keys` is the set of pressed keys out of
         "WSADQE", `mouse_delta` the cursor movement in pixels since the last call.  Moves / rotates the camera and
         recalculates the view — the previous-frame matrices are NOT touched (only commit_frame / an explicit pose reset
         do that), which is what makes ReSTIR's temporal reprojection land on a different pixel.  Returns `moved`."""
-        delta = (F(mouse_delta[0]) * F(0.002), F(mouse_delta[1]) * F(0.002))
-        moved = False
-        up = np.array([0, 1, 0], dtype=F)
-        fwd = self.forward.astype(F)
-        right = np.cross(fwd, up).astype(F)
-        speed, ts = F(5.0), F(ts)
-        keys = keys.upper()
-        if "W" in keys:
-            self.position = (self.position + fwd * speed * ts).astype(F); moved = True
-        elif "S" in keys:
-            self.position = (self.position - fwd * speed * ts).astype(F); moved = True
-        if "A" in keys:
-            self.position = (self.position - right * speed * ts).astype(F); moved = True
-        elif "D" in keys:
-            self.position = (self.position + right * speed * ts).astype(F); moved = True
-        if "Q" in keys:
-            self.position = (self.position - up * speed * ts).astype(F); moved = True
-        elif "E" in keys:
-            self.position = (self.position + up * speed * ts).astype(F); moved = True
-        if delta[0] != 0.0 or delta[1] != 0.0:
-            pitch, yaw = delta[1] * F(0.3), delta[0] * F(0.3)                    # GetRotationSpeed() = 0.3
-            q = _quat_normalize(_quat_mul(_quat_angle_axis(-pitch, right), _quat_angle_axis(-yaw, up)))
-            self.forward = _quat_rotate(q, fwd)
-            moved = True
-        if moved:                                                                # RecalculateView(): prev_* stay
-            self.view = look_at(self.position, self.position + self.forward, (0, 1, 0))
-            self.inverse_view = inverse(self.view)
+        moved = bool(self._lib.fyprt_host_camera_on_update(self._h, float(ts), keys.upper().encode(), float(mouse_delta[0]), float(mouse_delta[1])))
+        self._pull()
         return moved
 
     def ray_directions(self):
@@ -241,19 +203,15 @@ class Scene:
     def _to_world(positions, normals, pos, rotation, scale_):
         """Mesh::UpdateWorldTransform + the vertex loop of Scene::AddNewMeshToScene / SceneManager (Scene.cpp:42-51,
         SceneManager.cpp:30-41): transform = T * yawPitchRoll(ry, rx, rz) * S, position / w, normal with w = 0, normalised."""
-        m = _matmul(_matmul(translate(pos), yaw_pitch_roll(math.radians(rotation[1]), math.radians(rotation[0]), math.radians(rotation[2]))), scale(scale_))
-        p4 = (m[0][None, :] * positions[:, 0:1] + m[1][None, :] * positions[:, 1:2]) + (m[2][None, :] * positions[:, 2:3] + m[3][None, :])
-        wp = (p4[:, :3] / p4[:, 3:4]).astype(F)
-        n4 = (m[0][None, :] * normals[:, 0:1] + m[1][None, :] * normals[:, 1:2]) + (m[2][None, :] * normals[:, 2:3])
-        nl = np.sqrt((n4[:, 0] * n4[:, 0] + n4[:, 1] * n4[:, 1]) + n4[:, 2] * n4[:, 2])
-        wn = (n4[:, :3] * (F(1) / nl)[:, None]).astype(F)
-        return wp, wn
+        v = np.zeros(len(positions), dtype=VERTEX_DTYPE)
+        v["position"], v["normal"] = positions, normals
+        w = to_world(mesh_matrix(pos, rotation, scale_), v)
+        return w["position"].copy(), w["normal"].copy()
 
     def mesh_matrix(self, mesh_index):
         """Mesh::worldTransformMatrix of a mesh ([col][row] float32): T * yawPitchRoll(ry, rx, rz) * S (Mesh::UpdateWorldTransform)."""
         tr = self.mesh_transforms[mesh_index]
-        rot = tr["rotation"]
-        return _matmul(_matmul(translate(tr["pos"]), yaw_pitch_roll(math.radians(rot[1]), math.radians(rot[0]), math.radians(rot[2]))), scale(tr["scale"]))
+        return mesh_matrix(tr["pos"], tr["rotation"], tr["scale"])
 
     def add_new_mesh_to_scene(self, positions, normals, uvs, indices, pos=(0, 0, 0), rotation=(0, 0, 0),
                               scale_=(1, 1, 1), material_index=0):
@@ -286,7 +244,8 @@ class Scene:
         return self.scene_manager
 
     def init_scene_emissive_triangles(self):  # Scene.cpp:209-221
-        em = np.array([float(np.dot(m.get_emission(), m.get_emission())) > 0.0 for m in self.materials])
+        lib = _host_lib()
+        em = np.array([bool(lib.fyprt_host_is_emissive(_f3(m.emission_color).ctypes.data, float(m.emission_power))) for m in self.materials], dtype=bool)
         self.emissive_triangles = np.nonzero(em[self.triangles["materialIndex"]])[0].astype(np.uint32)
         return self.emissive_triangles
 

@@ -1,8 +1,9 @@
 """the host producers of the kernel inputs — Scene::AddNewMeshToScene's transform, Mesh::UpdateWorldTransform
-and SceneManager::PerformAllSceneUpdates (Scene.cpp:9-92, SceneManager.cpp:6-130) — in their two mirrors: the C++ one the
-facade uses (host/HostTypes.h, through host/scene_check) and the Python one the tests and bench.py use (scene.py).
-The reference has no fixtures for these and glm is unpinned, so the pins are: the two mirrors agree bit for bit, a mesh moved
-through the SceneManager equals the same mesh added with the new transform, and the reference's queue quirks are kept."""
+and SceneManager::PerformAllSceneUpdates (Scene.cpp:9-92, SceneManager.cpp:6-130).  Since r03 there is ONE implementation of their
+arithmetic, host/HostTypes.h: the C++ facade uses it directly (here through host/scene_check) and the Python containers of scene.py
+call it through libfyprt_host.so.  The reference has no fixtures for these and glm is unpinned, so the pins are: the Python path
+(its own bookkeeping: vertex ranges, queues, material rewrites) produces what the C++ Scene / SceneManager produce, bit for bit; a mesh
+moved through the SceneManager equals the same mesh added with the new transform; and the reference's queue quirks are kept."""
 import subprocess
 from pathlib import Path
 
@@ -41,7 +42,7 @@ def _cpp(scene_check, *args):
 
 
 @pytest.mark.parametrize("tr", [(0, -3, 0, 90, 0, 0, 1, 1, 1), (1.5, 0.25, -2, 33, 71, -12, 0.5, 2, 1.25), (0, 0, 0, 0, 0, 0, 1, 1, 1)])
-def test_cpp_and_python_mirrors_agree(scene_check, tr):
+def test_cpp_scene_and_python_containers_agree(scene_check, tr):
     head, rows = _cpp(scene_check, *tr)
     assert head[:2] == ["first_call_dirty 1", "second_call_dirty 0"]          # the queues start with 20 default entries (SceneManager.h:25-26)
     sc = Scene()
@@ -99,3 +100,19 @@ def test_dirty_flag_drives_a_re_upload():
     after = ctx.export_bvh()
     assert not np.array_equal(before["tris"]["v0"], after["tris"]["v0"])       # the moved mesh's triangles are where they now are
     ctx.close()
+
+
+def test_camera_is_the_facades_camera():
+    """scene.Camera is a handle to HostTypes.h's Camera: explicit pose -> previous-frame matrices reset (Camera.cpp:108-116), OnUpdate moves
+    without touching them, commit_frame copies; the inverse matrices really are inverses."""
+    cam = scenes.hall_camera(320, 180)
+    assert np.array_equal(cam.prev_view, cam.view) and np.array_equal(cam.prev_projection, cam.projection)
+    before = cam.view.copy()
+    assert cam.on_update(0.016, "WD", (12.0, -7.0)) is True
+    assert not np.array_equal(cam.view, before) and np.array_equal(cam.prev_view, before)          # reprojection now sees last frame's view
+    cam.commit_frame()
+    assert np.array_equal(cam.prev_view, cam.view)
+    for m, inv in ((cam.view, cam.inverse_view), (cam.projection, cam.inverse_projection)):
+        prod = m.astype(np.float64).T @ inv.astype(np.float64).T                                  # [col][row] storage = transposed matrices
+        assert np.allclose(prod, np.eye(4), atol=1e-5)
+    assert cam.on_update(0.016, "", (0.0, 0.0)) is False
