@@ -279,7 +279,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{workload}_{W}x{H}_{capi.TECHNIQUE_NAMES[tech]}_1spp", "triangles": int(len(sc.triangles)),
                    "meshes": len(sc.meshes), "emissive_triangles": int(len(sc.emissive_triangles)),
-                   "rays_per_frame": int(total_rays), "temporal_reuse": True, "spatial_reuse": True,
+                   "rays_per_frame": int(total_rays), "rays_counted": "TraceRay-equivalent traversals actually run (a ReSTIR DI shadow query whose pixel is black in every outcome is answered without one and NOT counted)",
+                   "temporal_reuse": True, "spatial_reuse": True,
                    "parallelism": f"row-bands x{N}" + ((f" + {halo}-row halo {args.halo} + RCCL grouped broadcast per band (C ABI)" if args.transport == "cabi" else
                                                          f" + {halo}-row halo recompute + RCCL all-gather(RGBA8)") if N > 1 else ""),
                    "bvh_build_s": round(build_s, 2)},
@@ -292,7 +293,9 @@ def main():
         pixels_band = (r1 - r0) * W
         if restir:
             if tech == 7:
-                p2_pixels = int(cs.part_rays[2])                       # DI: exactly one shadow ray per Part-2 pixel (trace launch)
+                # Part-2 pixels = pixels Part 1 left a reservoir for (M > 0).  Not every one of them traces a shadow ray: a ray whose pixel is
+                # black in every outcome is answered without one (tuning key 18) — `rays` counts traced rays only.
+                p2_pixels = int(np.count_nonzero(ctx.read_buffer(capi.BUF_DI)["M"].reshape(H, W)[r0:r1]))
             else:
                 p2_pixels = int(np.count_nonzero(ctx.read_buffer(capi.BUF_GI)["M"].reshape(H, W)[r0:r1]))
             p1_pixels = p1_rows * W

@@ -418,7 +418,7 @@ class Context:
         nodes = np.empty(nn.value, dtype=BVH_NODE_DTYPE)
         tris = np.empty(nt.value, dtype=BVH_TRI_DTYPE)
         self._check(self.lib.fyprt_export_bvh(self.h, _ptr(nodes), C.byref(nn), _ptr(tris), C.byref(nt), C.byref(root), C.byref(depth)))
-        return {"nodes": nodes, "tris": tris, "root": root.value, "max_stack": depth.value, "stack_budget": self.get_tuning(8)}
+        return {"nodes": nodes, "tris": tris, "root": root.value, "max_stack": depth.value, "stack_budget": self.get_tuning(8), "skip_dead_rays": self.get_tuning(18)}
 
     def export_lighttrees(self, mesh_count: int):
         tc, tr, bt = C.c_uint32(), C.c_uint32(), C.c_uint32()

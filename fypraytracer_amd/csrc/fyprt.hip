@@ -90,7 +90,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, 0, 0, 0, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, 0, 0, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
@@ -740,6 +740,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
     st.candidateCount = (uint32_t)s->light_candidate_count; st.randSeed = s->rand_seed;
     st.useTemporal = s->use_temporal_reuse ? 1u : 0u; st.useSpatial = s->use_spatial_reuse ? 1u : 0u;
     st.historyLimit = (uint8_t)s->temporal_history_limit; st.numNeighbors = (uint8_t)s->spatial_neighbor_num; st.radius = (uint8_t)s->spatial_neighbor_radius;
+    st.skipDeadRays = c->tuning[18] ? 1u : 0u;
     DevFrame fr;
     fr.accum = c->accum.p; fr.image = c->externalImage ? c->externalImage : c->image.p; fr.payload = c->payload.p; fr.depth = c->depth.p;
     fr.normalPrev = c->normalFlip ? c->normalB.p : c->normalA.p; fr.normalCur = c->normalFlip ? c->normalA.p : c->normalB.p;
@@ -968,6 +969,10 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                         c->traceOcc = n; c->traceOccLds = ldsBytes;
                     }
                     perCU = c->traceOcc;
+                    // pipelined frames: the persistent grid shares the chip with Part 1 + setup of the NEXT frame; with every slot a CU has
+                    // (6 workgroups) those start late and run in extra rounds — 4 per CU leave them room: an eighth of the frame (a multi-GPU
+                    // band) renders in 0.228 instead of 0.252 ms, the whole frame in the same 0.888 ms (profiles/README.md r03)
+                    if (overlap && perCU > 4) perCU = 4;
                 }
                 // persistent grid: as many workgroups as the chip holds — but not more than the band has tasks for (one lane per task): a narrow
                 // multi-GPU band would otherwise park idle workgroups on the LDS / wave slots the next frame's Part 1 is waiting for
@@ -1200,7 +1205,7 @@ int fyprt_set_tuning(fyprt_context* c, int key, int value) {
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
     static const int lo[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[24] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2, 1024, 2, 0, 0, 0, 0, 0, 0};
+    static const int hi[24] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2, 1024, 2, 1, 0, 0, 0, 0, 0};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

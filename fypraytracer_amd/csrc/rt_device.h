@@ -70,7 +70,10 @@ struct DevFrame {
 
 struct DevSettings {   // RenderingSettings.h:5-22 with the kernel-side uint8 casts already applied
     f3 sky; uint32_t maxBounces, sampleCount, candidateCount, randSeed, useTemporal, useSpatial, historyLimit, numNeighbors, radius;
+    uint32_t skipDeadRays;   // ReSTIR DI Part 2: a shadow ray whose pixel is black in EVERY outcome (both candidate radiances exactly zero: reservoir weight 0,
+                             // a light facing away, ...) is not traced — same pixel, fewer rays (tuning key 18; the reference traces it, R.cu:2010-2031)
 };
+RT_DEV bool zero3(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }      // +-0 only: a NaN or an infinity is not zero
 
 struct Hit { float t, u, v; int32_t tri; };
 

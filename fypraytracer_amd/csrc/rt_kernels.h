@@ -348,12 +348,15 @@ __global__ __launch_bounds__(kBlock) void k_di_part2(DevScene sc, DevCamera cam,
     const float triAreaPDF = 1.0f / tri_area(g);
     const float sa = triAreaPDF * (dist * dist);
     const f3 T = ((brdf * cx) * cy) / sa;
-    const ShadowHit hit = trace_shadow<COUNT>(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, ti, stk);
+    f3 Lvis = splat3(0.0f);                                          // the pixel's radiance if the light is visible / if the ray escapes
+    { const Mat lm = load_mat(sc, g.mat); if (length(emission(lm)) > 0.0f) { Lvis = T * emission(lm); Lvis = Lvis * R.W; } }
+    const f3 Lsky = T * st.sky;
     f3 radiance = splat3(0.0f);
-    if ((uint32_t)hit.objectIndex == ti && hit.hitDistance >= 0.0f) {
-        const Mat lm = load_mat(sc, g.mat);
-        if (length(emission(lm)) > 0.0f) { radiance = T * emission(lm); radiance = radiance * R.W; }
-    } else if (hit.hitDistance < 0.0f) radiance = T * st.sky;
+    if (!(st.skipDeadRays && zero3(Lvis) && zero3(Lsky))) {          // (black in every outcome: no ray, DevSettings::skipDeadRays)
+        const ShadowHit hit = trace_shadow<COUNT>(sc, pos3(pp) + nrm3(pp) * 1e-12f, dir, ti, stk);
+        if ((uint32_t)hit.objectIndex == ti && hit.hitDistance >= 0.0f) radiance = Lvis;
+        else if (hit.hitDistance < 0.0f) radiance = Lsky;
+    }
     fr.depth[i] = pp.hitDistance;
     { f2 on; on.x = own.nx; on.y = own.ny; store_rec(fr.dprevWrite + i, pp.hitDistance, on, R); }
     epilogue(fr, i, rgb1(radiance));

@@ -211,9 +211,10 @@ __global__ __launch_bounds__(kBlock) RT_SETUP_WAVES void k_di_part2_setup(DevSce
         if (length(lem) > 0.0f) { Lvis = T * lem; Lvis = Lvis * R.W; }                         // R.cu:2018-2027
         Lsky = T * st.sky;                                                                     // R.cu:2028-2031
         ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
+        if (st.skipDeadRays && zero3(Lvis) && zero3(Lsky)) ti = kNoRayTask;                    // black whatever the ray finds: a task without a ray (colour Lvis = 0)
         // the shadow ray's distance to its own light triangle (trace_shadow's first step), computed HERE at full lane utilisation so that
         // a refill of the persistent trace kernel is two loads and three reciprocals (<= 0: the ray misses its light -> closest-hit fallback)
-        tLight = light_tri_distance(sc, ti, ro, rd);
+        else tLight = light_tri_distance(sc, ti, ro, rd);
         fr.depth[i] = pp.hitDistance;
         { f2 on; on.x = own.nx; on.y = own.ny; store_rec(fr.dprevWrite + i, pp.hitDistance, on, R); }
     }

@@ -90,6 +90,7 @@ void orc_set_product_bvh(orc_handle* h, const void* nodes, uint32_t nodeCount, c
 // deepest traversal stack the product-order restatement has used so far, and a knob to force its resume-entry path
 int orc_product_max_stack(orc_handle* h) { return h->prodTracer->maxTop; }
 void orc_set_product_stack_budget(orc_handle* h, int budget) { h->prodTracer->stackBudget = budget; }
+void orc_set_skip_dead_rays(orc_handle* h, int on) { h->rp->skipDeadShadowRays = on != 0; }     // product twin only
 // event log of the product-order traversal (tools/wave_sim.py): start with on = 1 (render with ONE thread), read with orc_take_events
 static std::vector<uint8_t> g_events;
 void orc_record_events(orc_handle* h, int on) { g_events.clear(); h->prodTracer->events = on ? &g_events : nullptr; }

@@ -285,6 +285,7 @@ struct Frame {
 
 struct Renderer {
     const Scene& sc; const Tracer& tracer; Camera cam; Settings st; Frame fr;
+    bool skipDeadShadowRays = false;   // the product's tuning key 18 (only meaningful beside the ProductTracer: ray counts must be the product's)
     Renderer(const Scene& s, const Tracer& t) : sc(s), tracer(t) {}
 
     vec3 RayDirection(uint32_t x, uint32_t y) const {                            // Camera.cpp:136-153
@@ -592,12 +593,25 @@ struct Renderer {
         float solidAnglePDF = triAreaPDF * (dist * dist);
         vec3 T = brdf * cx * cy / solidAnglePDF;
         Ray ray{pp.worldPosition + pp.worldNormal * 1e-12f, dir};
+        // product twin only: the product does not trace a shadow ray whose pixel is black in every outcome (both candidate radiances
+        // exactly zero) — the pixel is the reference's, the ray counters are the product's
+        bool dead = false;
+        if (skipDeadShadowRays) {
+            vec3 Lvis = v3(0.0f);
+            const Material& m = sc.materials[et.materialIndex];
+            if (m.GetEmissionRadiance() > 0.0f) { Lvis = T * m.GetEmission(); Lvis *= R.weightEmissive; }
+            const vec3 Lsky = T * st.skyColor;
+            auto zero = [](const vec3& v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; };
+            dead = zero(Lvis) && zero(Lsky);
+        }
+        if (!dead) {
         Payload hit = tracer.TraceTo(ray, ti, c);
         bool vis = (uint32_t)hit.objectIndex == ti;
         if (vis && hit.hitDistance >= 0.0f) {
             const Material& m = sc.materials[et.materialIndex];
             if (m.GetEmissionRadiance() > 0.0f) { radiance = T * m.GetEmission(); radiance *= R.weightEmissive; }
         } else if (hit.hitDistance < 0.0f) radiance = T * st.skyColor;
+        }
         fr.depth[i] = pp.hitDistance;
         fr.diPrev[i] = R;
         return v4(radiance, 1.0f);

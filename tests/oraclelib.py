@@ -112,6 +112,7 @@ class Oracle:
         n, t = np.ascontiguousarray(bvh["nodes"]), np.ascontiguousarray(bvh["tris"])
         self.lib.orc_set_product_bvh(self.h, n.ctypes.data, len(n), t.ctypes.data, len(t), int(bvh["root"]))
         self.set_product_stack_budget(bvh.get("stack_budget", 31))     # the budget the product's stack rule runs with
+        self.lib.orc_set_skip_dead_rays(self.h, int(bvh.get("skip_dead_rays", 1)))   # ... and its tuning key 18
 
     def product_max_stack(self):
         return int(self.lib.orc_product_max_stack(self.h))

@@ -20,6 +20,7 @@ VARIANTS = [
     {6: 0}, {6: 40}, {7: 16},                       # node-loop quorum (shadow rays / every other kernel)
     {14: 1}, {14: 2},                               # Part-2 setup: speculative neighbour gathers / neighbourhood hot fields in LDS
     {15: 1}, {15: 2},                               # wavefront stages' ray kernel: persistent / one thread per ray
+    {18: 0}, {18: 0, 1: 0},                         # every ReSTIR DI shadow ray traced, also those whose pixel is black in every outcome (the default skips them)
 ]
 
 
@@ -77,6 +78,35 @@ def test_fused_small_scene_frame_equals_the_stage_frame(scene_name, tech):
     for (img, acc), counts in outs[1:]:
         assert np.array_equal(img, outs[0][0][0]) and np.array_equal(acc, outs[0][0][1], equal_nan=True)
         assert counts == outs[0][1]
+
+
+def test_dead_shadow_rays_are_not_traced_and_nothing_changes():
+    """Tuning key 18 (default on): a ReSTIR DI shadow ray whose pixel is black whatever the ray finds — reservoir weight zero, light facing
+    away, black sky — is answered without a ray.  Same pixels, fewer rays; with a sky that is not black the miss outcome is not zero and
+    every ray is traced again."""
+    mk_scene, mk_cam = SCENES["hall_small"]
+    sc, W, H = mk_scene(), 160, 96
+    cam = mk_cam(W, H)
+    out = {}
+    for sky in ((0.0, 0.0, 0.0), (0.3, 0.4, 0.5)):
+        for skip in (1, 0):
+            ctx = capi.Context(0)
+            ctx.resize(W, H); ctx.upload_scene(sc); ctx.set_camera(cam)
+            ctx.set_tuning(18, skip)
+            ctx.set_ray_counting(True)
+            st = settings_for(capi.RESTIR_DI, sky_color=sky)
+            rays = 0
+            for f in range(3):
+                st.rand_seed = f + 1
+                rays += ctx.render(st).part_rays[2]
+            out[(sky, skip)] = (ctx.readback(), rays)
+            ctx.close()
+        (a, ra), (b, rb) = out[(sky, 1)], out[(sky, 0)]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True)
+        if sky == (0.0, 0.0, 0.0):
+            assert ra < rb                                       # some rays were dead
+        else:
+            assert ra <= rb
 
 
 def test_async_frames_equal_blocking_frames():
@@ -170,7 +200,7 @@ def test_light_sorted_tasks_with_pipelined_async_frames():
 
 def test_tuning_values_are_range_checked():
     ctx = capi.Context(0)
-    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (24, 0), (-1, 0)):
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (17, 3), (18, 2), (24, 0), (-1, 0)):
         with pytest.raises(capi.FyprtError):
             ctx.set_tuning(key, bad)
     ctx.set_tuning(5, 64)

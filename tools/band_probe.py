@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One band of an N-way row split of the bench frame, rendered alone with asynchronous frames (what a rank of bench.py --gpus N does):
-   usage: python tools/band_probe.py <n> <rank> [frames] [mode: recompute|exchange]   — for a kernel-trace timeline (tools/timeline_run.sh)."""
+   usage: python tools/band_probe.py <n> <rank> [frames] [mode: recompute|exchange] [key=value ...]   — for a kernel-trace timeline (tools/timeline_run.sh)."""
 import sys
 import time
 from pathlib import Path
@@ -10,6 +10,7 @@ from fypraytracer_amd import capi, multigpu, scenes  # noqa: E402
 n, rank = int(sys.argv[1]), int(sys.argv[2])
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 mode = sys.argv[4] if len(sys.argv) > 4 else "recompute"
+knobs = [kv.split("=") for kv in sys.argv[5:]]
 W, H = 1920, 1080
 sc, cam = scenes.hall_scene(), scenes.hall_camera(W, H)
 ctx = capi.Context(0)
@@ -20,6 +21,8 @@ for f in range(2):
 halo = multigpu.halo_rows(st, 7, n)
 y0, y1 = multigpu.band_rows(H, n, rank)
 ctx.set_tuning(13, 1 if mode == "exchange" else 0)
+for k, v in knobs:
+    ctx.set_tuning(int(k), int(v))
 ctx.set_rows(y0, y1, halo)
 for f in range(8):
     st.rand_seed = f + 3; ctx.render_async(st)
@@ -28,4 +31,4 @@ t0 = time.perf_counter()
 for f in range(frames):
     st.rand_seed = 11 + f; ctx.render_async(st)
 ctx.synchronize()
-print("band", (y0, y1), "halo", halo, mode, "wall ms/frame", round((time.perf_counter() - t0) / frames * 1e3, 4), "parts", [round(x, 4) for x in ctx.frame_timings(0)[0]])
+print("band", (y0, y1), "halo", halo, mode, knobs, "wall ms/frame", round((time.perf_counter() - t0) / frames * 1e3, 4), "parts", [round(x, 4) for x in ctx.frame_timings(0)[0]])

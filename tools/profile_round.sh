@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${P}_stats" -- python3 "$R/bench.py" --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/${P}_bench.json" 2> "$OUT/${P}_stats.err"
 echo "stats pass done"
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAVES"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAVES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/${P}_$tag" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --set 11=0 > /dev/null 2> "$OUT/${P}_$tag.err" || echo "pass $tag FAILED"
   echo "$tag pass done"

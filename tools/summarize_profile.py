@@ -76,6 +76,12 @@ def main():
             y["valu_wave_instructions"] = int(m("SQ_INSTS_VALU"))
         if m("SQ_THREAD_CYCLES_VALU") is not None and m("SQ_ACTIVE_INST_VALU"):
             y["lane_utilisation"] = round(m("SQ_THREAD_CYCLES_VALU") / (64.0 * m("SQ_ACTIVE_INST_VALU")), 3)
+        if m("TCP_TOTAL_CACHE_ACCESSES_sum") is not None:
+            y["l1_lookups_per_launch"] = int(m("TCP_TOTAL_CACHE_ACCESSES_sum"))        # vector-L1 tag look-ups (what the microbenchmark's gather rate is measured in)
+            if m("TCP_TCC_READ_REQ_sum") is not None and m("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                y["l1_hit_rate"] = round(1.0 - m("TCP_TCC_READ_REQ_sum") / m("TCP_TOTAL_CACHE_ACCESSES_sum"), 4)
+        if m("SQ_INSTS_VMEM_RD") is not None:
+            y["vmem_read_wave_instructions"] = int(m("SQ_INSTS_VMEM_RD"))
         if m("SQ_WAIT_ANY") is not None and m("SQ_WAVE_CYCLES"):
             y["wait_any_over_wave_cycles"] = round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 3)
         x["derived"] = y
