@@ -363,7 +363,10 @@ __global__ __launch_bounds__(kBlock) void k_nee_emit(DevScene sc, DevSettings st
             else { const float wD = pdfDirect / gmax(pdfB + pdfDirect, 1e-12f); C = ((((wD * T) * brdf) * cx) * em) / pdfDirect; }
         }
         const f3 origin = hpos + hnrm * 1e-12f;
-        store_ray(raysOut, j * raysPer, ray_shadow(sc, origin, ld, i, pl.tri));
+        // the consume step adds C if the light is reached and nothing otherwise: a C of exactly zero (the surface faces away from the picked
+        // light, a black emitter) makes the shadow ray's answer irrelevant — its slot then holds no ray (kRayNone, DevSettings::skipDeadRays)
+        if (st.skipDeadRays && zero3(C)) { RayRec none = ray_closest(origin, ld, i); none.q1.w = __int_as_float((int)kRayNone); store_ray(raysOut, j * raysPer, none); }
+        else store_ray(raysOut, j * raysPer, ray_shadow(sc, origin, ld, i, pl.tri));
         float pdfBRDF = S[2].w;
         if (maxBounces != 1u) {
             const f3 nd = sample_brdf(hnrm, -rd, albedo, mat.metallic, mat.roughness, seed, pdfBRDF);
@@ -576,6 +579,7 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
             const float pdf = jac > 0.0f ? nlen / jac : 0.0f;
             const float tol = gmax(1e-4f, distR * 1e-3f);
             out = ray_visible(nsp, dR, i, distR, tol);
+            if (st.skipDeadRays && pdf == 0.0f) out.q1.w = __int_as_float((int)kRayNone);     // a merge weight of zero whatever the ray finds (R.cu:2356-2368): no ray in this slot
             S[0] = make_float4(__int_as_float((int)src), spdf, Wr, wSum);
             S[1] = make_float4(__int_as_float((int)M), __int_as_float((int)seed), __int_as_float((int)n), __int_as_float((int)Z));
             S[2] = make_float4(__int_as_float((int)ni), pdf, NwSum, __int_as_float((int)NM));

@@ -289,7 +289,15 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        the geometry test served from there; same results; measured slower as well (profiles/README.md r02).
  * key 15: ray kernel of the wavefront stages (techniques 0-6, ReSTIR GI): 1 = persistent waves with lane refill, 2 = one thread per ray,
  *        0 (default) = by tree size: one thread per ray below 65 536 triangles, where rays are too cheap for the refill machinery to pay.
- * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 13: 0..1, keys 12, 14, 15: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64, key 8: 0..31. */
+ * key 16: EXPERIMENT, acts only in a -DRT_TOPCACHE build: the first N nodes of the (area-ordered) node array are also kept in LDS by the
+ *        ReSTIR DI traversal kernels (0..1024).  Measured a net loss (profiles/README.md r03); compiled out by default.
+ * key 17: techniques 0-5 on a tree of fewer than 65 536 triangles render the whole frame in ONE launch (k_path_fused: one thread per pixel,
+ *        the stage path's step functions): 0 (default) = by tree size, 1 = always the stages, 2 = always fused.  Same results.
+ * key 18: 1 (default) = a ReSTIR DI Part-2 shadow ray whose pixel is black in EVERY outcome (both candidate radiances exactly zero) is
+ *        not traced; 0 = every Part-2 pixel traces its ray as Renderer.cu:2010-2031 does.  Same pixels; fewer rays are counted.
+ *        Also on by default since r03: key 2 = 0 uses at most 4 workgroups per CU for the persistent ReSTIR DI grid while frames are pipelined.
+ * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 13, 18: 0..1, keys 12, 14, 15, 17: 0..2, key 2: 0..16, keys 5, 6, 7: 0..64,
+ * key 8: 0..31, key 16: 0..1024; keys 19..23 are reserved (0). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the
  * traversal must use too). */
@@ -324,7 +332,9 @@ int fyprt_selftest_math(fyprt_context* ctx, uint64_t* mismatches3, uint32_t* fir
  *   0 recompute: every band also runs Part 1 on its halo rows; frame 1 equals the single-GPU frame, later frames differ (unbiased)
  *                near band borders because the halo rows have no temporal history;
  *   1 exchange : the bands send each other the Part-1 records (and the temporal history) of those rows — a static-camera
- *                sequence then equals the single-GPU sequence bit for bit on every frame, and Part 1 does no duplicate work. */
+ *                sequence then equals the single-GPU sequence bit for bit on every frame, and Part 1 does no duplicate work
+ *                (shown for the peer-copy transport fyprt_group_*; the RCCL transport fyprt_comm_* runs the same plan but has only
+ *                executed with a one-rank communicator so far: INTEGRATION.md, "Verification status"). */
 typedef struct fyprt_group fyprt_group;
 /* --- one process, one context per GPU (a C++ host such as the reference's MainLayer): peer copies, no collective library */
 int fyprt_group_create(fyprt_context** contexts, int n, const uint32_t* row_bounds, fyprt_group** out);

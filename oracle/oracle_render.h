@@ -423,7 +423,22 @@ struct Renderer {
                 float dist = length(ld);
                 ld /= dist;
                 Ray shadow{hit.worldPosition + hit.worldNormal * 1e-12f, ld};
-                Payload sh = tracer.TraceTo(shadow, sl.emitterIndex, c);
+                // product twin only (skipDeadShadowRays): the product prepares the direct term before the ray and does not trace a ray whose term
+                // is exactly zero — the sum below would not change; the pixel is the reference's, the ray counters are the product's
+                bool dead = false;
+                if (skipDeadShadowRays) {
+                    vec3 ln = TriNormal(n0, n1, n2);
+                    vec3 brdf = CalculateBRDF(hit.worldNormal, -pathRay.direction, ld, albedo, mat.metallic, mat.roughness);
+                    float cx = gmax(dot(ld, hit.worldNormal), 0.0f);
+                    float cy = gmax(dot(-ld, ln), 1e-12f);
+                    float lsa = (1.0f / TriArea(p0, p1, p2)) * (dist * dist) / cy;
+                    float pd = sl.pmf * lsa;
+                    float pb = BRDFHemispherePDF(hit.worldNormal, -pathRay.direction, ld, albedo, mat.metallic, mat.roughness);
+                    vec3 emission = sc.materials[lt.materialIndex].GetEmission();
+                    vec3 add = (maxBounces == 1) ? T * brdf * cx * emission / pd : (pd / gmax(pb + pd, 1e-12f)) * T * brdf * cx * emission / pd;
+                    dead = add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
+                }
+                Payload sh = dead ? Miss() : tracer.TraceTo(shadow, sl.emitterIndex, c);
                 if (sh.hitDistance > 0.0f && (uint32_t)sh.objectIndex == sl.emitterIndex) {
                     vec3 ln = TriNormal(n0, n1, n2);
                     vec3 brdf = CalculateBRDF(hit.worldNormal, -pathRay.direction, ld, albedo, mat.metallic, mat.roughness);
@@ -712,7 +727,8 @@ struct Renderer {
                 Ray ray{N.sample.samplePoint, normalize(R.sample.visiblePoint - N.sample.samplePoint)};
                 float dist = length(R.sample.visiblePoint - N.sample.samplePoint);
                 float tol = gmax(1e-4f, dist * 1e-3f);
-                bool visible = tracer.TraceVisible(ray, dist, tol, c);
+                // (product twin: a visibility ray whose merge weight is zero already is not traced — same reservoir, the product's ray count)
+                bool visible = (skipDeadShadowRays && pdf == 0.0f) ? true : tracer.TraceVisible(ray, dist, tol, c);
                 if (!visible) pdf = 0.0f;
                 GI_Merge(R, N, pdf, seed);
             }
