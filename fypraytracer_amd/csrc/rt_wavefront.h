@@ -519,8 +519,6 @@ RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_
                 const float4* t = q.rays + (size_t)task * 3;
                 const float4 t0 = t[0], t1 = t[1], t2 = t[2];
                 o = mk3(t0.x, t0.y, t0.z); d = mk3(t1.x, t1.y, t1.z); mode = (uint32_t)__float_as_int(t1.w);
-                if (mode == kRayNone) q.hits[task] = make_float4(-1.0f, 0.0f, 0.0f, __int_as_float(-1));      // no ray in this slot: the lane stays idle until the next refill
-                else {
                 pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
                 hitTri = -1; hu = 0.0f; hv = 0.0f; closestMode = true; tL = 3.402823466e+38f;
                 if (mode == kRayVisible) { closestMode = false; hu = t2.x - t2.y; tL = t2.x + t2.y; }     // hu = dist - tol, interval end = dist + tol; hv: 0 nothing yet, 1 found, -1 blocked
@@ -528,9 +526,10 @@ RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_
                 cut = tL * 1.000001f;
                 if (COUNT) { nBox = 0; nNode = 0; nTri = (mode != kRayClosest && mode != kRayVisible) ? 1u : 0u; }
                 top = 0; lane_push(lds, top, kExit);
-                cur = (sc.triCount == 0 || ray_not_finite(o, d)) ? kExit : sc.rootRef;
+                // (a slot without a ray — kRayNone — is a closest-hit record that never starts: it leaves through the ordinary exit with the
+                // "nothing hit" answer (-1, 0, 0, -1), uncounted)
+                cur = (sc.triCount == 0 || mode == kRayNone || ray_not_finite(o, d)) ? kExit : sc.rootRef;
                 active = true;
-                }
             }
         }
         if (__ballot(active) == 0ull) { if (!more) break; else continue; }
@@ -564,7 +563,7 @@ RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_
                 if (mode == kRayVisible) res = make_float4(hv > 0.0f ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
                 else res = make_float4(hitTri < 0 ? -1.0f : tL, hu, hv, __int_as_float(hitTri));
                 q.hits[task] = res;
-                if (COUNT) {
+                if (COUNT && mode != kRayNone) {
                     atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
                     atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri);
                     atomicAdd(sc.rayCounter + 3, (unsigned long long)((mode == kRayVisible) ? (hv > 0.0f ? 1 : 0) : (hitTri < 0 ? 0 : 1)));
