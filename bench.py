@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # (VALU_MIX_CYCLES: the static instruction mix of the traversal loop priced with those measurements, tools/isa_mix.py).
 SIMDS = 256 * 4
 VALU_PEAK_2CYC_GINSTR = SIMDS * 2.4 / 2.0          # 1228.8 G wave-instructions / s: every instruction a 2-cycle one
-VALU_MIX_CYCLES = 3.8                              # measured issue cycles per instruction of the traversal loop's mix (see above)
+VALU_MIX_CYCLES = 4.1                              # measured issue cycles per instruction of the traversal loop's mix (see above)
 VALU_PEAK_MIX_GINSTR = SIMDS * 2.4 / VALU_MIX_CYCLES
 VL1_PEAK_LOOKUPS_PER_CLK_CU = 1.46                 # divergent 16-byte lane loads served by the vector L1, measured (microbench "gather", 16 KB table)
 KERNEL_NAMES = {7: ["k_di_part1", "k_di_part2_setup", "k_di_part2_trace"], 8: ["gi_part1_stages", "gi_part2_stages"]}

@@ -82,8 +82,10 @@ def split_rays(buf):
 class Wave:
     """64 lanes x `slots` rays per lane; a ray = a row of the padded event matrix E (0 node visit, 100 + k leaf with k triangle tests, -1 end)"""
 
-    def __init__(self, E, first, count, slots=1):
+    def __init__(self, E, first, count, slots=1, postpone=0):
         self.E, self.next, self.end, self.slots = E, first, first + count, slots
+        self.postpone = postpone            # leaves a lane may carry along while it keeps walking inner nodes ("speculative" traversal)
+        self.held = np.zeros((64, slots), dtype=np.int64)
         self.task = np.full((64, slots), -1, dtype=np.int64)
         self.pos = np.zeros((64, slots), dtype=np.int64)
         self.tri = np.zeros((64, slots), dtype=np.int64)
@@ -98,10 +100,12 @@ class Wave:
         """enter leaves (a leaf's triangle count becomes pending triangle rounds), retire finished rays"""
         while True:
             e = self.cur()
-            at = (self.task >= 0) & (self.tri == 0) & (e >= 100)
+            at = (self.task >= 0) & (self.held <= self.postpone) & (e >= 100)
             if not at.any():
                 break
-            self.tri = np.where(at, e - 100, self.tri)
+            self.tri = np.where(at, self.tri + e - 100, self.tri)
+            self.held = np.where(at, self.held + 1, self.held)
+            self.held = np.where(self.tri == 0, 0, self.held)          # leaves without a triangle test are nothing to carry
             self.pos = np.where(at, self.pos + 1, self.pos)
         e = self.cur()
         done = (self.task >= 0) & (self.tri == 0) & (e < 0)
@@ -110,7 +114,7 @@ class Wave:
     def want(self):
         e = self.cur()
         act = self.task >= 0
-        return act & (self.tri == 0) & (e == 0), act & (self.tri > 0)
+        return act & (self.held <= self.postpone) & ((self.tri == 0) | (self.postpone > 0)) & (e == 0), act & (self.tri > 0)
 
     @staticmethod
     def first_slot(m):
@@ -130,6 +134,7 @@ class Wave:
     def tri_round(self, t):
         t = self.first_slot(t)
         self.tri = np.where(t, self.tri - 1, self.tri)
+        self.held = np.where(self.tri == 0, 0, self.held)
         self.cycles += C_TRI; self.lane_cycles += C_TRI * int(t.sum())
 
     def idle_slots(self):
@@ -140,14 +145,14 @@ class Wave:
         got = min(len(free), self.end - self.next)
         for k in range(got):
             l, sl = free[k]
-            self.task[l, sl] = self.next + k; self.pos[l, sl] = 0; self.tri[l, sl] = 0
+            self.task[l, sl] = self.next + k; self.pos[l, sl] = 0; self.tri[l, sl] = 0; self.held[l, sl] = 0
         self.next += got
         self.cycles += C_REFILL; self.lane_cycles += C_REFILL * min(64, got)
 
 
-def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, greedy=False, tri_weight=1.0, select_cost=0, select_cost_tri=None):
+def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, greedy=False, tri_weight=1.0, select_cost=0, select_cost_tri=None, postpone=0):
     """the persistent kernel's loop (rt_wavefront.h) on one wave; greedy: every round is the kind with the larger (lanes / cost)"""
-    w = Wave(E, first, count, slots)
+    w = Wave(E, first, count, slots, postpone)
     while True:
         more = w.next < w.end
         if more and (w.idle_slots() >= refill_lanes * slots or not (w.task >= 0).any()):
@@ -246,7 +251,28 @@ def main():
             c += cc; l += ll
         print(json.dumps({"queue_order": oname, "policy": "kernel q24 r24", "issue_cycles_per_ray": round(c / (nwaves * per), 1), "lane_utilisation": round(l / (c * 64), 3)}), flush=True)
     E = matrix(orders.get("tiles (the setup kernel's order: 16x16 workgroups, 8x8 waves)", orders["row-major"]))
-    for name, kw in policies:
+    # "Speculative" traversal: a lane that reaches a leaf carries it along and keeps walking inner nodes until its next leaf (or the end), so more
+    # lanes share a node round.  A shadow ray that the carried leaf would have ended (occluded) walks on in vain until the leaf phase: priced by
+    # appending the ray's mean node run between leaves to every ray that ends on a leaf (pessimistic: not every such ray is occluded).
+    gaps = [int((q == 0).sum()) / max(1, int((q >= 100).sum())) for q in shadow]
+    Es = np.full((E.shape[0], E.shape[1] + 16), -1, dtype=np.int16); Es[:, :E.shape[1]] = E
+    order = orders.get("tiles (the setup kernel's order: 16x16 workgroups, 8x8 waves)", orders["row-major"])
+    for k, src in enumerate(order):
+        q = shadow[src]
+        if len(q) and q[-1] >= 100:
+            g = min(16, int(round(gaps[src])))
+            Es[k, len(q):len(q) + g] = 0
+    for name, kw in [("kernel q24 r24, one leaf carried along", dict(quorum=24, refill_lanes=24, postpone=1)), ("kernel q16 r24, one leaf carried", dict(quorum=16, refill_lanes=24, postpone=1)),
+                     ("kernel q32 r24, one leaf carried", dict(quorum=32, refill_lanes=24, postpone=1)), ("kernel q24 r24, two leaves carried", dict(quorum=24, refill_lanes=24, postpone=2)),
+                     ("greedy r16, one leaf carried", dict(greedy=True, refill_lanes=16, postpone=1))]:
+        cyc = lane = opt = 0
+        for wv in range(nwaves):
+            c, l = run_kernel_policy(Es, wv * per, per, **kw)
+            c2, _ = run_kernel_policy(E, wv * per, per, **kw)
+            cyc += c; lane += l; opt += c2
+        nr = nwaves * per
+        print(json.dumps({"policy": name, "issue_cycles_per_ray_if_no_ray_walked_in_vain": round(opt / nr, 1), "issue_cycles_per_ray": round(cyc / nr, 1), "lane_utilisation": round(lane / (cyc * 64), 3), "rays": nr}), flush=True)
+    for name, kw in policies[:1]:
         t0 = time.time()
         cyc = lane = 0
         for wv in range(nwaves):
