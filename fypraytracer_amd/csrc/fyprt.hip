@@ -269,6 +269,14 @@ static int upload(fyprt_context* c, void* dst, const void* src, size_t bytes) {
 }
 
 
+// the node array back from the device, into HOST form (rt_host.h: inner references are indices on the host, byte offsets on the device)
+static int download_nodes(fyprt_context* c) {
+    if (c->hostBvh.nodes.empty()) return FYPRT_OK;
+    HIPCHK(c, hipMemcpy(c->hostBvh.nodes.data(), c->nodes.p, c->hostBvh.nodes.size() * 64, hipMemcpyDeviceToHost));
+    rth::nodes_to_host_form(c->hostBvh.nodes.data(), c->hostBvh.nodes.size());
+    return FYPRT_OK;
+}
+
 // the refit pass over the whole tree (rt_refit.h): leaf triangles from the per-triangle positions, then boxes + quantisation
 // level by level, bottom level first
 static int run_refit(fyprt_context* c) {
@@ -368,14 +376,13 @@ static int build_device_lbvh(fyprt_context* c, const fyprt_vertex* verts, uint32
         if (count) hipLaunchKernelGGL(k_lbvh_levels, dim3((count + 127u) / 128u), dim3(128), 0, c->stream, wide.p, first, count);
     }
     HIPCHK(c, hipGetLastError());
-    if (total >= (1u << 26)) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: too many nodes for the node index range");
+    if (total >= rth::kMaxNodes) return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: too many nodes for the node reference range");
     HIPCHK(c, c->nodes.alloc((size_t)total * 4));
     HIPCHK(c, hipMemcpyAsync(c->nodes.p, wide.p, (size_t)total * 64, hipMemcpyDeviceToDevice, c->stream));
     rth::SceneBVH& b = c->hostBvh; b = rth::SceneBVH();
     b.nodes.resize(total); b.tris.resize(nT); b.rootRef = 0; b.levels = nLevels;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(b.nodes.data(), c->nodes.p, (size_t)total * 64, hipMemcpyDeviceToHost));      // topology + meta: the level grouping needs it
-    return FYPRT_OK;
+    return download_nodes(c);                                                                        // topology + meta: the level grouping needs it
 }
 
 int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
@@ -405,11 +412,13 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     bool deviceBuild = !c->hostOnly && c->tuning[12] != 0 && s->triangle_count > 4;
     auto hostBuild = [&]() -> int {
         rth::BuildSceneBVH(s->vertices, tb, s->triangle_stride, s->meshes, s->mesh_count, c->hostBvh);
-        if (c->hostBvh.levels > rth::kStackBudget || c->hostBvh.nodes.size() >= (size_t)(1u << 26))
+        if (c->hostBvh.levels > rth::kStackBudget || c->hostBvh.nodes.size() >= (size_t)rth::kMaxNodes)
             return c->fail(FYPRT_EINVAL, "fyprt_upload_scene: acceleration structure (" + std::to_string(c->hostBvh.levels) + " levels, " +
                            std::to_string(c->hostBvh.nodes.size()) + " nodes) exceeds the traversal stack / node index range");
         HIPCHK(c, c->nodes.alloc(c->hostBvh.nodes.size() * 4)); HIPCHK(c, c->leafTris.alloc(c->hostBvh.tris.size() * 3));
-        if (upload(c, c->nodes.p, c->hostBvh.nodes.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
+        std::vector<rth::Node> dn;                                        // the array in device form (inner references = byte offsets)
+        if (!c->hostOnly) { dn = c->hostBvh.nodes; rth::nodes_to_device_form(dn.data(), dn.size()); }
+        if (upload(c, c->nodes.p, dn.data(), c->nodes.bytes()) || upload(c, c->leafTris.p, c->hostBvh.tris.data(), c->leafTris.bytes())) return FYPRT_EHIP;
         return FYPRT_OK;
     };
     if (!deviceBuild) { const int rc = hostBuild(); if (rc != FYPRT_OK) return rc; }
@@ -459,7 +468,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
         const int rc = run_refit(c);
         if (rc != FYPRT_OK) return rc;
         HIPCHK(c, sync_all(c));
-        HIPCHK(c, hipMemcpy(c->hostBvh.nodes.data(), c->nodes.p, c->hostBvh.nodes.size() * 64, hipMemcpyDeviceToHost));
+        { const int rc2 = download_nodes(c); if (rc2 != FYPRT_OK) return rc2; }
         HIPCHK(c, hipMemcpy(c->hostBvh.tris.data(), c->leafTris.p, c->hostBvh.tris.size() * 48, hipMemcpyDeviceToHost));
     }
     // materials (Material.cuh:7-16 -> 3 quads)
@@ -533,7 +542,7 @@ int fyprt_upload_scene(fyprt_context* c, const fyprt_scene_desc* s) {
     if (upload(c, c->ltLeafOfTri.p, leafOfTri.data(), c->ltLeafOfTri.bytes())) return FYPRT_EHIP;
     DevScene& d = c->dsc;
     d.ltLeafOfTri = c->ltLeafOfTri.p;
-    d.nodes = c->nodes.p; d.leafTris = c->leafTris.p; d.rootRef = c->hostBvh.rootRef; d.triCount = nT;
+    d.nodes = c->nodes.p; d.leafTris = c->leafTris.p; d.rootRef = rth::device_ref(c->hostBvh.rootRef); d.triCount = nT;
     d.triPos = c->triPos.p; d.triShade = c->triShade.p; d.mats = c->mats.p; d.textures = c->texTable.p; d.textureCount = s->texture_count;
     d.emissive = c->emissive.p; d.emissiveCount = (uint32_t)em.size();
     d.ltTlas = c->ltTlas.p; d.ltTlasCount = (uint32_t)lt.tlas.size(); d.ltTlasRoot = lt.tlasRoot;
@@ -1164,7 +1173,7 @@ int fyprt_export_bvh(fyprt_context* c, void* nodes64, uint32_t* node_count, void
     if (!c->haveScene) return c->fail(FYPRT_ESTATE, "fyprt_export_bvh before fyprt_upload_scene");
     if (c->hostBvhStale && !c->hostOnly) {              // the device refitted the tree: read it back
         HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_all(c));
-        if (!c->hostBvh.nodes.empty()) HIPCHK(c, hipMemcpy(c->hostBvh.nodes.data(), c->nodes.p, c->hostBvh.nodes.size() * 64, hipMemcpyDeviceToHost));
+        { const int rc = download_nodes(c); if (rc != FYPRT_OK) return rc; }
         if (!c->hostBvh.tris.empty()) HIPCHK(c, hipMemcpy(c->hostBvh.tris.data(), c->leafTris.p, c->hostBvh.tris.size() * 48, hipMemcpyDeviceToHost));
         c->hostBvhStale = false;
     }

@@ -160,7 +160,8 @@ RT_DEV void order_keys(double& a, double& b) {                  // (a, b) <- (mi
 // tested again when that entry is popped (then against a cut that can only have shrunk).  In resume mode a level costs one
 // entry, so by induction pending + levels(node) <= kStackBudget holds at every visit and the 32-entry LDS stack cannot
 // overflow for any tree of <= kStackBudget levels (bvh_build.cpp) — without bounding how wide the nodes may be.
-constexpr int32_t kResumeBase = 0x40000000;     // references >= this: resume entry, (ref - base) = node << 4 | slot mask
+constexpr int32_t kResumeBase = 0x40000000;     // references >= this: resume entry = base | node byte offset | mask of the slots still to visit
+constexpr uint32_t kNodeOffsetMask = 0x3FFFFFC0u; // an inner reference is the node's byte offset in the array (rt_host.h: device form), < 2^30, 64-byte aligned
 constexpr int kStackBudget = kStackDepth - 1;   // one entry is the exit sentinel
 // returns the next reference to visit (a child, or the popped stack top when no child is hit)
 // COUNT: instrumented variant (child-box tests and node visits per ray; fyprt_set_ray_counting) — the production kernels are
@@ -170,17 +171,18 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     // resume entries are rare: one wave-uniform test keeps their decoding (and, below, their slot masks) off the common path — the kernels
     // are bound by instruction issue, every instruction and every exec-mask region of a visit is paid on each of ~18 visits per ray
     const bool anyResumed = __ballot(cur >= kResumeBase) != 0ull;
-    int32_t node = cur; uint32_t allow = 0xFu;
-    if (anyResumed) { const bool resumed = cur >= kResumeBase; node = resumed ? ((cur - kResumeBase) >> 4) : cur; allow = resumed ? ((uint32_t)cur & 0xFu) : 0xFu; }
+    const uint32_t off = (uint32_t)cur & kNodeOffsetMask;            // the node's byte offset: one fast-class instruction, resumed or not
+    uint32_t allow = 0xFu;
+    if (anyResumed) allow = (cur >= kResumeBase) ? ((uint32_t)cur & 0xFu) : 0xFu;
     float4 q0, q1, q2; float2 q3;
 #ifdef RT_TOPCACHE
-    if ((uint32_t)node < st.topCount) {
-        const float4* n = st.top4 + (size_t)node * 4;
+    if ((off >> 6) < st.topCount) {
+        const float4* n = st.top4 + (off >> 4);
         q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
     } else
 #endif
     {
-        const float4* n = nodes + (size_t)node * 4;
+        const float4* n = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);     // uniform base + 32-bit lane offset
         q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = *reinterpret_cast<const float2*>(n + 3);
     }
     const uint32_t ex = (uint32_t)__float_as_int(q0.w), cnt = (ex >> 24) & 7u, levels = ex >> 27;
@@ -241,7 +243,7 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
     else if (s1h < kMissHi) {                                         // two or more hits and no room to push them one by one
         const uint32_t hit = (h0 < kMissHi ? 1u : 0u) | (h1 < kMissHi ? 2u : 0u) | (h2 < kMissHi ? 4u : 0u) | (h3 < kMissHi ? 8u : 0u);
         const uint32_t nearest = (c0 == r0) ? 1u : (c1 == r0) ? 2u : (c2 == r0) ? 4u : 8u;     // the nearest child's slot (references of hit slots are distinct)
-        st.push(kResumeBase + (int32_t)(((uint32_t)node << 4) | (hit & ~nearest)));
+        st.push(kResumeBase | (int32_t)(off | (hit & ~nearest)));
     }
 #undef RT_PUSH3
     return (s0h < kMissHi) ? r0 : st.pop();

@@ -32,6 +32,16 @@ struct SceneBVH {
 };
 
 constexpr uint32_t kStackBudget = 31;   // kernels: 32-entry LDS stack, one entry is the exit sentinel
+// Child references of inner nodes have two forms.  HOST form (SceneBVH, fyprt_export_bvh, the oracle's twin): the node's index.  DEVICE form
+// (the node array in HBM, DevScene::rootRef, the traversal stack): the node's BYTE OFFSET, index << 6 — a visit then forms its address with
+// one v_and and a 32-bit offset on the array's base instead of a resume-entry decode and a 64-bit shift + add (rt_device.h: node_step; r03).
+// Leaf codes (negative) are the same in both forms; offsets stay below 2^30 (bit 30 marks a resume entry), so a tree has < 2^24 nodes.
+constexpr int kNodeRefShift = 6;
+constexpr uint32_t kMaxNodes = 1u << 24;
+inline int32_t device_ref(int32_t hostRef) { return hostRef >= 0 ? (int32_t)((uint32_t)hostRef << kNodeRefShift) : hostRef; }
+inline int32_t host_ref(int32_t deviceRef) { return deviceRef >= 0 ? (deviceRef >> kNodeRefShift) : deviceRef; }
+inline void nodes_to_device_form(Node* n, size_t count) { for (size_t i = 0; i < count; ++i) for (int k = 0; k < 4; ++k) n[i].child[k] = device_ref(n[i].child[k]); }
+inline void nodes_to_host_form(Node* n, size_t count) { for (size_t i = 0; i < count; ++i) for (int k = 0; k < 4; ++k) n[i].child[k] = host_ref(n[i].child[k]); }
 // Two-level build: one SAH BLAS per mesh (world-space triangles, <= 4 per leaf) and a SAH TLAS
 // over the mesh bounds whose leaves are the BLAS roots, merged into one binary tree and then collapsed
 // into 4-wide nodes with quantised child boxes.  Replaces BVH::ConstructBVH_SAH

@@ -166,7 +166,7 @@ __global__ void k_lbvh_collapse(const RadixNode* rn, const float* box, const uin
             const uint32_t w = atomicAdd(counters + 0, 1u);
             const uint32_t o = atomicAdd(counters + 1, 1u);
             out[o] = CollapseItem{ch[i], w, first};
-            ref[i] = (int32_t)w;
+            ref[i] = (int32_t)(w << 6);                                 // device form of an inner reference: the node's byte offset (rt_host.h)
         }
         first += sp;
     }
@@ -255,7 +255,7 @@ __global__ void k_lbvh_levels(float4* nodes, uint32_t first, uint32_t count) {
     const int32_t child[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
     uint32_t below = 0;
     for (uint32_t i = 0; i < cnt; ++i) if (child[i] >= 0) {
-        const uint32_t cl = ((uint32_t)__float_as_int(nodes[(size_t)child[i] * 4].w)) >> 27;
+        const uint32_t cl = ((uint32_t)__float_as_int(nodes[(size_t)(child[i] >> 6) * 4].w)) >> 27;
         below = cl > below ? cl : below;
     }
     const uint32_t levels = 1u + below;

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(128) void k_refit_level(float4* nodes, const uint32
         for (int a = 0; a < 3; ++a) { b.lo[a] = big; b.hi[a] = -big; }
         if (i >= cnt) { cb[i] = b; continue; }
         if (child[i] >= 0) {
-            const float4 l = nodeBox[(size_t)child[i] * 2], h = nodeBox[(size_t)child[i] * 2 + 1];
+            const size_t ci = (size_t)(child[i] >> 6);                // device form: byte offset of the child node (rt_host.h)
+            const float4 l = nodeBox[ci * 2], h = nodeBox[ci * 2 + 1];
             b.lo[0] = l.x; b.lo[1] = l.y; b.lo[2] = l.z; b.hi[0] = h.x; b.hi[1] = h.y; b.hi[2] = h.z;
         } else {
             const uint32_t code = (uint32_t)~child[i], first = code >> 2, m = (code & 3u) + 1u;
