@@ -142,11 +142,19 @@ RT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu)
 // (the entry parameter is clamped to a tiny positive number instead of zero: as the high word of a sort key it must be a normal number, see node_step)
 constexpr float kNearClamp = 1e-30f;
 // entry / exit parameter of two children (x = first, y = second of the pair) from their near / far plane parameters
+// (the exit side is written as the two instructions it should be: through __builtin_fminf the compiler re-canonicalises `cut` — a value it
+// cannot see the origin of inside the loop — with an extra v_max_f32 in every visit; the instructions' own NaN rule is minnum's)
+RT_DEV float min3_with_cut(float a, float b, float c, float cut) {
+    float t, r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(c), "v"(cut));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
 RT_DEV void slab_of_pair(v2f nx, v2f fx, v2f ny, v2f fy, v2f nz, v2f fz, float cut, float& n0, float& f0, float& n1, float& f1) {
     n0 = __builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), __builtin_fmaxf(nz.x, kNearClamp));
-    f0 = __builtin_fminf(__builtin_fminf(fx.x, fy.x), __builtin_fminf(fz.x, cut));
+    f0 = min3_with_cut(fx.x, fy.x, fz.x, cut);
     n1 = __builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), __builtin_fmaxf(nz.y, kNearClamp));
-    f1 = __builtin_fminf(__builtin_fminf(fx.y, fy.y), __builtin_fminf(fz.y, cut));
+    f1 = min3_with_cut(fx.y, fy.y, fz.y, cut);
 }
 RT_DEV void order_keys(double& a, double& b) {                  // (a, b) <- (min, max): exact on the bit patterns of positive normal doubles
     double lo, hi;
@@ -237,9 +245,9 @@ RT_DEV int32_t node_step(const float4* nodes, int32_t budget, int32_t cur, const
 #define RT_PUSH3() do { st.lds[st.top * kBlock] = r3; st.top += (s3h < kMissHi) ? 1 : 0; \
                         st.lds[st.top * kBlock] = r2; st.top += (s2h < kMissHi) ? 1 : 0; \
                         st.lds[st.top * kBlock] = r1; st.top += (s1h < kMissHi) ? 1 : 0; } while (0)
-    const bool room = (st.top - 1) + 2 + (int)levels <= budget;
-    if (__ballot(!room) == 0ull) RT_PUSH3();                          // the common case, wave-uniform: no exec-mask region around the pushes
-    else if (room) RT_PUSH3();
+    const uint64_t noRoom = __ballot((st.top - 1) + 2 + (int)levels > budget);
+    if (noRoom == 0ull) RT_PUSH3();                                   // the common case, wave-uniform: no exec-mask region around the pushes
+    else if (((noRoom >> (threadIdx.x & 63u)) & 1ull) == 0ull) RT_PUSH3();
     else if (s1h < kMissHi) {                                         // two or more hits and no room to push them one by one
         const uint32_t hit = (h0 < kMissHi ? 1u : 0u) | (h1 < kMissHi ? 2u : 0u) | (h2 < kMissHi ? 4u : 0u) | (h3 < kMissHi ? 8u : 0u);
         const uint32_t nearest = (c0 == r0) ? 1u : (c1 == r0) ? 2u : (c2 == r0) ? 4u : 8u;     // the nearest child's slot (references of hit slots are distinct)
@@ -304,11 +312,13 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase, const
     Stack st; st.lds = ldsBase; st.top = 0; st.top4 = top4; st.topCount = top4 ? sc.topCount : 0u; st.push(kExit);
     int32_t cur = sc.rootRef;
     while (true) {
-        while (cur >= 0) {
+        bool walk = cur >= 0;                           // (one compare per round serves the loop condition and the quorum ballot)
+        while (walk) {
             cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, closestInfl, st, nBox, nNode);
             // lanes that reached a leaf wait outside this loop; once only a few lanes are still walking inner nodes,
             // stop and let everybody test their leaves (keeps SIMD lanes busy; pure scheduling, results unchanged)
-            if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+            walk = cur >= 0;
+            if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
         }
         if (cur >= 0) continue;
         if (cur == kExit) break;
@@ -355,9 +365,11 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
     r.hitDistance = tL; r.objectIndex = (int32_t)lightTri;
     bool occluded = false;
     while (!occluded) {
-        while (cur >= 0) {
+        bool walk = cur >= 0;
+        while (walk) {
             cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode);
-            if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+            walk = cur >= 0;
+            if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
         }
         if (cur >= 0) continue;
         if (cur == kExit) break;

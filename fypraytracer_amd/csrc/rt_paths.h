@@ -598,6 +598,91 @@ RT_DEV bool gi2_step(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     return false;
 }
 
+// ============================================================ ReSTIR GI Part 2 in ONE launch (tuning key 19)
+// The staged Part 2 is 2 x neighbours + 1 launches whose shade steps are HBM-bound: every step moves the pixel's state (64-80 B each way), a
+// 48-byte ray record and a 16-byte result through memory, and reads the payload again.  Here one thread keeps its pixel for the whole
+// neighbour loop — same expressions, same random draws in the same order as gi2_step — with the visibility ray traced in place
+// (trace_one, the one-thread-per-ray traversal of the small-scene path): the state never leaves registers, nothing but the payload, the
+// reservoirs and the neighbours' hot records is read, nothing but the final reservoir, depth and the pixel is written.  The wave walks in
+// rounds — every lane looks for its next accepted neighbour, then the lanes that found one trace together — so a ray's node loop runs with
+// all the lanes that still have a ray; a lane whose neighbours are used up idles until the wave's last lane is done (what the staged
+// path's compaction avoids, at the price of the traffic above).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_gi2_fused(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, const uint32_t* list, const uint32_t* listCount) {
+    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
+    const uint32_t count = *listCount;
+    for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < count; base += gridDim.x * (uint32_t)kBlock) {   // (block-uniform trips: node_step's ballots see whole waves)
+        const uint32_t j = base + threadIdx.x;
+        const bool inside = j < count;
+        const uint32_t i = inside ? list[j] : 0u, x = i % fr.W, y = i / fr.W;
+        uint32_t src = i, seed = 0, n = 0, Z = 0, M = 0; float spdf = 0.0f, Wr = 0.0f, wSum = 0.0f, pdp = 0.0f; f3 rvp = splat3(0.0f), pn = splat3(0.0f);
+        if (inside) {
+            const Payload pp = fr.payload[i];
+            pdp = pp.hitDistance; pn = nrm3(pp);
+            const GIRes own = fr.gi[i];
+            spdf = own.s.pdf; Wr = own.W; wSum = own.wSum; M = own.M; rvp = mk3(own.s.vp[0], own.s.vp[1], own.s.vp[2]);
+            seed = i * (fr.frameIndex + 213u + st.randSeed);
+            if (st.useSpatial) { const float plen = length(lo3(own.s)); Z = plen > 0.0f ? M : 0u; }
+        }
+        while (true) {
+            bool have = false; uint32_t ni = 0, NM = 0; float pdf = 0.0f, NwSum = 0.0f, distR = 0.0f; f3 nvp = splat3(0.0f), nsp = splat3(0.0f), dR = splat3(0.0f);
+            if (inside && st.useSpatial) {
+                for (; n < st.numNeighbors; ++n) {                                   // gi2_step's search for the next accepted neighbour
+                    ni = neighbor_index(cam, fr.W, x, y, st.radius, seed);
+                    const float4* nq = fr.giHot + (size_t)ni * 4;
+                    const float4 hot = nq[0];
+                    const float nd = hot.x, nlen = hot.w;
+                    f2 nnrm; nnrm.x = hot.y; nnrm.y = hot.z;
+                    if ((nd > 1.1f * pdp || nd < 0.9f * pdp) || (double)dot(pn, oct_decode(nnrm)) < 0.906 || nlen == 0.0f) continue;
+                    const float4 n1 = nq[1], n2 = nq[2], n3 = nq[3];
+                    NM = (uint32_t)__float_as_int(n1.w); NwSum = n2.w;
+                    Z += NM;
+                    f2 sne; sne.x = n3.x; sne.y = n3.y;
+                    const f3 sn = oct_decode(sne);
+                    nvp = xyz(n1); nsp = xyz(n2);
+                    const f3 dQ = normalize(nvp - nsp);
+                    const float cosQ = dot(sn, dQ);
+                    dR = normalize(rvp - nsp);
+                    const float cosR = dot(sn, dR);
+                    const float jl = cosQ > 0.0f ? cosR / cosQ : 0.0f;
+                    const float distQ = length(nvp - nsp); distR = length(rvp - nsp);
+                    const float jr = distR > 0.0f ? (distQ * distQ) / (distR * distR) : 0.0f;
+                    const float jac = jl * jr;
+                    pdf = jac > 0.0f ? nlen / jac : 0.0f;
+                    have = true;
+                    break;
+                }
+            }
+            if (__ballot(have) == 0ull) break;                                       // no lane of the wave has a neighbour left
+            if (have) {
+                // the visibility ray (R.cu:2356-2366); a merge weight of zero whatever the ray finds is not traced (DevSettings::skipDeadRays)
+                bool visible = true;
+                if (!(st.skipDeadRays && pdf == 0.0f)) {
+                    const float tol = gmax(1e-4f, distR * 1e-3f);
+                    visible = trace_one<COUNT>(sc, nsp, dR, kRayVisible, distR, tol, s_stack + threadIdx.x).x != 0.0f;
+                }
+                if (!visible) pdf = 0.0f;
+                // gi_merge(R, N, pdf, seed) on the counters (ReSTIR_GI_Reservoir.cu:36-43 -> :5-34)
+                const uint32_t prevM = M;
+                const float w = (pdf * NwSum) * (float)NM;
+                wSum += w; M += 1u;
+                if (rnd(seed) < w / wSum) { src = ni; spdf = pdf; rvp = nvp; }
+                M = prevM + NM;
+                ++n;
+            }
+        }
+        if (inside) {
+            GIRes R = fr.gi[src];                                                   // the selected sample, with the reservoir's own pdf / counters
+            R.s.pdf = spdf; R.M = M; R.wSum = wSum; R.W = Wr;
+            if (st.useSpatial) R.W = R.s.pdf > 0.0f ? R.s.pdf / ((float)Z * R.s.pdf) : 0.0f;
+            const f3 radiance = lo3(R.s) * R.W;
+            fr.depth[i] = pdp;
+            fr.giPrev[i] = R;
+            epilogue(fr, i, rgb1(radiance));
+        }
+    }
+}
+
 // ============================================================ small scenes: the whole frame of techniques 0-5 in ONE launch
 // A scene whose rays cost a handful of node visits (Cornell box: 3; the reference's banana: 8) gains nothing from re-packing lanes
 // between bounces, and every one of the 2 x steps + 1 stage launches pays its own fill, drain and one-wave-round latency: the

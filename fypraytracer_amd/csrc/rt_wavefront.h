@@ -391,9 +391,11 @@ RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const Sh
         // ---------------- traverse until enough lanes have finished to make a refill worthwhile
         while (true) {
             // inner nodes
-            while (active && r.cur >= 0) {
+            bool walk = active && r.cur >= 0;                  // (one compare per round serves the loop condition and the quorum ballot)
+            while (walk) {
                 { Stack st; st.lds = lds; st.top = r.top; st.top4 = top4; st.topCount = sc.topCount; r.cur = node_step<COUNT>(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, r.nNode); r.top = st.top; }
-                if ((uint32_t)__popcll(__ballot(r.cur >= 0)) < sc.nodeQuorum) break;
+                walk = r.cur >= 0;
+                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
             }
             // leaves
             if (active && r.cur < 0 && r.cur != kExit) {
@@ -534,9 +536,11 @@ RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_
         }
         if (__ballot(active) == 0ull) { if (!more) break; else continue; }
         while (true) {
-            while (active && cur >= 0) {
+            bool walk = active && cur >= 0;
+            while (walk) {
                 { Stack st; st.lds = lds; st.top = top; cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode); top = st.top; }
-                if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+                walk = cur >= 0;
+                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
             }
             if (active && cur < 0 && cur != kExit) {
                 const uint32_t code = (uint32_t)~cur, firstTri = code >> 2, cnt = (code & 3u) + 1u;
@@ -594,9 +598,11 @@ RT_DEV float4 trace_one(const DevScene& sc, f3 o, f3 d, uint32_t mode, float a0,
         int32_t cur = sc.rootRef;
         bool done = false;
         while (!done) {
-            while (cur >= 0) {
+            bool walk = cur >= 0;
+            while (walk) {
                 cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode);
-                if ((uint32_t)__popcll(__ballot(cur >= 0)) < sc.nodeQuorum) break;
+                walk = cur >= 0;
+                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
             }
             if (cur >= 0) continue;
             if (cur == kExit) break;
