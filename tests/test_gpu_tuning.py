@@ -80,6 +80,42 @@ def test_fused_small_scene_frame_equals_the_stage_frame(scene_name, tech):
         assert counts == outs[0][1]
 
 
+@pytest.mark.parametrize("scene_name", ["cornell", "hall_small"])
+@pytest.mark.parametrize("skip_dead", [1, 0])
+def test_gi_part2_in_one_launch_equals_the_stages(scene_name, skip_dead):
+    """Tuning key 19: ReSTIR GI Part 2 as ONE launch (1 = k_gi2_fused: a thread keeps its pixel for the whole neighbour loop, the visibility
+    ray traced in place; 2 = k_gi2_persistent: a lane owns a pixel, lanes without a ray in flight are serviced together) against the 2 x neighbours + 1 stage launches: every buffer a later frame reads (image, accumulation, depth, the
+    reservoirs that become the history) and every instrumentation count must be the stages', frame after frame (temporal reuse feeds on it)."""
+    mk_scene, mk_cam = SCENES[scene_name]
+    sc, W, H = mk_scene(), 136, 88                   # not a multiple of 16: partial tiles
+    cam = mk_cam(W, H)
+    outs = []
+    for mode, part1 in ((0, 0), (1, 0), (2, 0), (0, 1), (2, 1)):     # key 21 = 1: Part 1's bounce loop as one persistent launch too (k_gi1_persistent)
+        ctx = capi.Context(0)
+        ctx.resize(W, H)
+        ctx.upload_scene(sc)
+        ctx.set_camera(cam)
+        ctx.set_tuning(19, mode)
+        ctx.set_tuning(21, part1)
+        ctx.set_tuning(18, skip_dead)
+        ctx.set_ray_counting(True)
+        st = settings_for(capi.RESTIR_GI, light_bounces=2)
+        counts = []
+        for f in range(4):
+            st.rand_seed = f + 1
+            s = ctx.render(st)
+            counts.append((s.rays, s.box_tests, s.tri_tests, s.hits, s.node_visits, tuple(s.part_rays)))
+        bufs = [ctx.read_buffer(b) for b in (capi.BUF_DEPTH, capi.BUF_GI, capi.BUF_GI_PREV)]
+        outs.append((ctx.readback(), counts, bufs))
+        ctx.close()
+    (img0, acc0), counts0, bufs0 = outs[0]
+    for (img1, acc1), counts1, bufs1 in outs[1:]:
+        assert np.array_equal(img0, img1) and np.array_equal(acc0, acc1, equal_nan=True)
+        assert counts0 == counts1
+        for a, b in zip(bufs0, bufs1):
+            assert a.tobytes() == b.tobytes()
+
+
 def test_dead_shadow_rays_are_not_traced_and_nothing_changes():
     """Tuning key 18 (default on): a ReSTIR DI shadow ray whose pixel is black whatever the ray finds — reservoir weight zero, light facing
     away, black sky — is answered without a ray.  Same pixels, fewer rays; with a sky that is not black the miss outcome is not zero and
@@ -200,7 +236,7 @@ def test_light_sorted_tasks_with_pipelined_async_frames():
 
 def test_tuning_values_are_range_checked():
     ctx = capi.Context(0)
-    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (17, 3), (18, 2), (24, 0), (-1, 0)):
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (17, 3), (18, 2), (19, 3), (20, 65), (21, 2), (24, 0), (-1, 0)):
         with pytest.raises(capi.FyprtError):
             ctx.set_tuning(key, bad)
     ctx.set_tuning(5, 64)

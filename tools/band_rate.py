@@ -9,6 +9,7 @@ gather), so a split's frame time is its slowest band (+ the transfer estimate be
   --stripes S  (per-pixel techniques 0-6) interleaved stripes of S rows instead of bands: part r of n = fyprt_set_row_stripes(S, n, r).
 One JSON line per band and one summary line per split: {"n", "mode", "bounds", "slowest_band_ms", "speedup_vs_1"}."""
 import argparse
+import os
 import json
 import sys
 import time
@@ -40,6 +41,9 @@ def main():
     ctx.resize(W, H)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
+    for kv in filter(None, os.environ.get("FYPRT_TUNING", "").split(",")):      # e.g. FYPRT_TUNING=19=1 (experiments)
+        k, v = kv.split("=")
+        ctx.set_tuning(int(k), int(v))
     st = capi.Settings(technique=a.technique, light_bounces=1 if a.technique == 7 else 2, sky_color=(0, 0, 0), use_temporal_reuse=1, use_spatial_reuse=1)
     per_px_bytes = {7: (32, 32), 8: (96, 72)}.get(a.technique, (0, 0))     # Part-1 records, history (fyprt_multi.h)
 

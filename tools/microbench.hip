@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -161,12 +162,68 @@ static void run_gather(int numCUs, int wavesPerSimd, const float4* table, size_t
     CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
 }
 
-int main() {
+// ---------------------------------------------------------------- part C: the dependent load of a node visit
+// A traversal's visits form a chain: the next node's address comes out of the node just loaded.  Every lane chases its own chain through a
+// table of 64-byte records (all four quads loaded, the next index depends on all of them), the table filled with a pseudo-random
+// successor per record; `extra` dependent multiply-adds between two loads stand for the visit's arithmetic.  ns per link at 1 wave per SIMD
+// = the latency a lone wave pays per visit; at 6 waves per SIMD = what the chip delivers when latency is hidden.
+__global__ void k_fill_chain(uint32_t* table, uint32_t nRecords) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nRecords) return;
+    uint32_t s = i * 2654435761u + 97u; s ^= s >> 15; s *= 2246822519u; s ^= s >> 13; s *= 3266489917u; s ^= s >> 16;
+    uint32_t* r = table + (size_t)i * 16;
+    const uint32_t next = (uint32_t)(((unsigned long long)s * nRecords) >> 32);
+    r[0] = next & 0xFFFFu; r[4] = next >> 16; r[8] = 0u; r[12] = 0u;             // the successor is spread over the quads: all four loads are on the chain
+    for (int k = 0; k < 16; ++k) if (k != 0 && k != 4 && k != 8 && k != 12) r[k] = 0u;
+}
+template <int EXTRA>
+__global__ __launch_bounds__(256) void k_chase(const uint32_t* table, uint32_t nRecords, int iters, uint32_t* out) {
+    uint32_t idx = (uint32_t)(((unsigned long long)((blockIdx.x * 256u + threadIdx.x) * 2654435761u) * nRecords) >> 32);
+    float f = 1.0f;
+    for (int i = 0; i < iters; ++i) {
+        const uint4* p = reinterpret_cast<const uint4*>(table + (size_t)idx * 16);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        idx = (a.x | (b.x << 16)) + c.x + d.x;
+        if (EXTRA) {
+#pragma unroll
+            for (int k = 0; k < EXTRA; ++k) f = __builtin_fmaf(f, 1.0000001f, (float)(idx & 1u));
+            idx += (f > 3.0e38f) ? 1u : 0u;                                            // never true: keeps the arithmetic on the chain
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = idx + (uint32_t)f;
+}
+template <int EXTRA>
+static void run_chase(int numCUs, int wavesPerSimd, uint32_t* table, size_t tableBytes, uint32_t* dOut) {
+    const int iters = 300, blocks = numCUs * wavesPerSimd;
+    const uint32_t nRec = (uint32_t)(tableBytes / 64);
+    hipLaunchKernelGGL(k_fill_chain, dim3((nRec + 255) / 256), dim3(256), 0, 0, table, nRec);
+    hipLaunchKernelGGL((k_chase<EXTRA>), dim3(blocks), dim3(256), 0, 0, (const uint32_t*)table, nRec, 30, dOut);
+    CHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_chase<EXTRA>), dim3(blocks), dim3(256), 0, 0, (const uint32_t*)table, nRec, iters, dOut);
+    CHK(hipEventRecord(e1));
+    CHK(hipDeviceSynchronize());
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("{\"bench\": \"chase\", \"table_bytes\": %zu, \"waves_per_simd\": %d, \"dependent_fma_per_link\": %d, \"kernel_ms\": %.4f, \"ns_per_link\": %.1f, "
+                "\"lane_links_per_ns_chip\": %.2f}\n", tableBytes, wavesPerSimd, EXTRA, ms, ms * 1e6 / iters, (double)blocks * 256.0 * iters / (ms * 1e6));
+    CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+}
+
+int main(int argc, char** argv) {
+    const bool onlyChase = argc > 1 && std::strcmp(argv[1], "chase") == 0;
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int numCUs = prop.multiProcessorCount;
     std::printf("{\"bench\": \"device\", \"name\": \"%s\", \"cus\": %d, \"clock_khz\": %d}\n", prop.name, numCUs, prop.clockRate);
     float* dOut; unsigned long long* dCyc;
     CHK(hipMalloc((void**)&dOut, (size_t)numCUs * 8 * 256 * 4)); CHK(hipMalloc((void**)&dCyc, (size_t)numCUs * 8 * 4 * 8));
+    {
+        uint32_t* chain; CHK(hipMalloc((void**)&chain, (size_t)1 << 30));
+        for (size_t bytes : {(size_t)16 << 10, (size_t)1 << 20, (size_t)12 << 20, (size_t)64 << 20, (size_t)1 << 30})
+            for (int w : {1, 2, 6}) { run_chase<0>(numCUs, w, chain, bytes, (uint32_t*)dOut); run_chase<64>(numCUs, w, chain, bytes, (uint32_t*)dOut); }
+        CHK(hipFree(chain));
+    }
+    if (onlyChase) return 0;
     for (int w : {1, 2, 6}) IssueAll<kKinds - 1>::run(numCUs, w, dOut, dCyc);
     const size_t big = 64u << 20;
     float4* table; CHK(hipMalloc((void**)&table, big)); CHK(hipMemset(table, 0, big));
