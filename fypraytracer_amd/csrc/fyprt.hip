@@ -90,13 +90,12 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, /*19: ReSTIR GI Part 2 in one launch*/ 0, /*20: its service threshold*/ 48, /*21: ReSTIR GI Part 1's bounce loop in one persistent launch*/ 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, /*19: ReSTIR GI Part 2 in one launch*/ 2, /*20: its service threshold*/ 48, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
     int pathOcc = 0; size_t pathOccLds = 0;     // cached residency of k_trace_rays
     int gi2Occ = 0; size_t gi2OccLds = 0;       // ... of k_gi2_persistent
-    int gi1Occ = 0; size_t gi1OccLds = 0;       // ... of k_gi1_persistent
     DevBuf<uint32_t> refImage;                 // fyprt_compare_image's reference
     DevBuf<float4> shadowTasks; DevBuf<uint32_t> queueCounters, sortCounts, sortOffset, sortTotal, sortIndex; DevBuf<uint8_t> sortKeys; DevBuf<uint16_t> sortHist;
 
@@ -929,28 +928,8 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                     HIPCHK(c, hipMemsetAsync(cnt1, 0, (2 * L1 + 2 * L2) * sizeof(uint32_t), c->stream));
                     if (c->countRays) hipLaunchKernelGGL(k_gi_primary<true>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
                     else hipLaunchKernelGGL(k_gi_primary<false>, g1, block, ldsBytes, c->stream, c->dsc, c->dcam, fr, st, p1b, p1e, extraRow, c->wfPixels.p, cnt1);
-                    if (c->tuning[21] == 1) {
-                        // the bounce loop as one persistent launch (rt_paths.h: k_gi1_persistent): a lane owns a pixel of the primary kernel's list from its first sample to its reservoir
-                        DevScene tsc = c->dsc;
-                        tsc.nodeQuorum = (uint32_t)c->tuning[6];
-                        tsc.rayCounter = c->countRays ? c->rayCounter.p : nullptr;
-                        if (c->gi1OccLds != ldsBytes) {
-                            int nb = 0;
-                            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gi1_persistent<false>, kBlock, ldsBytes) != hipSuccess || nb <= 0) nb = 3;
-                            c->gi1Occ = nb; c->gi1OccLds = ldsBytes;
-                        }
-                        const int perCU = c->tuning[2] > 0 ? std::min(c->tuning[2], c->gi1Occ) : c->gi1Occ;
-                        GI1Queue gq{};
-                        gq.list = c->wfPixels.p; gq.count = cnt1; gq.head = cnt1 + L1 + 1; gq.part2List = c->wfPixels2.p; gq.part2Count = cnt2;
-                        gq.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); gq.refillLanes = (uint32_t)(c->tuning[20] > 0 ? c->tuning[20] : 48);
-                        gq.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); gq.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : gq.chunk);
-                        if (c->countRays) hipLaunchKernelGGL(k_gi1_persistent<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, c->dcam, fr, st, gq);
-                        else hipLaunchKernelGGL(k_gi1_persistent<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, c->dcam, fr, st, gq);
-                        HIPCHK(c, hipGetLastError());
-                    } else {
-                        StageRun r1{T_GI1, steps1, 1u, 5u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
-                        const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc;
-                    }
+                    StageRun r1{T_GI1, steps1, 1u, 5u, c->wfPixels.p, cnt1, cnt1 + L1, c->wfPixels2.p, cnt2, 0, nullptr, p1px};
+                    { const int rc = run_stage(r1); if (rc != FYPRT_OK) return rc; }
                     if (timed) HIPCHK(c, hipEventRecord(c->ev[ei++], c->stream));
                     if (phase == 1) { c->part1Pending = true; return c->hip(hipGetLastError(), "ReSTIR GI part 1"); }
                 }
@@ -1265,7 +1244,7 @@ int fyprt_set_tuning(fyprt_context* c, int key, int value) {
     // ranges: a value outside them could hang the persistent kernels (refill threshold above the wave size: no lane is ever
     // refilled) or index past a buffer, so it is refused here instead of trusted
     static const int lo[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int hi[24] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2, 1024, 2, 1, 2, 64, 1, 0, 0};
+    static const int hi[24] = {2, 1, 16, 1, 65536, 64, 64, 64, 31, 4096, 65536, 1, 2, 1, 2, 2, 1024, 2, 1, 2, 64, 0, 0, 0};
     if (value < lo[key] || value > hi[key])
         return c->fail(FYPRT_EINVAL, "fyprt_set_tuning: key " + std::to_string(key) + " accepts " + std::to_string(lo[key]) + ".." + std::to_string(hi[key]));
     c->tuning[key] = value;

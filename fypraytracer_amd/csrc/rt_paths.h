@@ -856,207 +856,6 @@ __global__ __launch_bounds__(kBlock) RT_GI2_WAVES void k_gi2_persistent(DevScene
     }
 }
 
-// ============================================================ ReSTIR GI Part 1's bounce loop as ONE PERSISTENT launch (tuning key 21)
-// The same idea for the bounce path (gi1_step): a lane owns a pixel of the primary kernel's list from its first BRDF sample to its
-// reservoir; throughput, radiance, seed and the sample point stay in registers, the closest-hit rays are traced in place with the other
-// lanes' rays, and the lanes without a ray in flight are serviced together (consume the hit, sample the next direction or finish:
-// initial reservoir, temporal reuse, the Part-2 record).  Same expressions and draws as gi1_step.  Finished pixels are appended to the
-// Part-2 list wave by wave (the list's order is not the stages' — nothing depends on it).
-struct GI1Queue { const uint32_t* list; const uint32_t* count; uint32_t* head; uint32_t* part2List; uint32_t* part2Count; uint32_t chunk, refillLanes, staticChunks, minChunk; };
-#ifndef RT_GI1_WAVES
-#define RT_GI1_WAVES __attribute__((amdgpu_waves_per_eu(5)))
-#endif
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) RT_GI1_WAVES void k_gi1_persistent(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, GI1Queue q) {
-    extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
-    int32_t* lds = s_stack + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = *q.count;
-    const uint32_t nWaves = gridDim.x * (uint32_t)(kBlock / 64), myWave = blockIdx.x * (uint32_t)(kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t share = (total + nWaves - 1u) / nWaves;
-    const uint32_t chunk = q.chunk, want1 = chunk * q.staticChunks;
-    const uint32_t first = share < want1 ? (share < 16u ? 16u : share) : want1;
-    const uint32_t dynBase = nWaves * first;
-    const bool hasDyn = dynBase < total;
-    bool more = total != 0u;
-    uint32_t chunkNext = myWave * first < total ? myWave * first : total;
-    uint32_t chunkEnd = (myWave + 1u) * first < total ? (myWave + 1u) * first : total;
-    // the lane's pixel and its bounce path
-    bool owns = false, tracing = false, verdict = false;
-    uint32_t i = 0, seed = 0; int b = 0;
-    f3 T = splat3(1.0f), Lo = splat3(0.0f), samplePoint = splat3(0.0f), sampleNormal = splat3(0.0f);
-    // the lane's ray
-    f3 o = splat3(0.0f), d = splat3(0.0f); RayPk pk = make_raypk(o, 1.0f, 1.0f, 1.0f);
-    float tL = 0.0f, cut = 0.0f, hu = 0.0f, hv = 0.0f; int32_t cur = kExit, hitTri = -1; int top = 0;
-    uint32_t nBox = 0, nTri = 0, nNode = 0;
-    while (true) {
-        const unsigned long long serviceable = __ballot(!tracing && (owns || more));
-        if (serviceable != 0ull && ((uint32_t)__popcll(serviceable) >= q.refillLanes || __ballot(tracing) == 0ull)) {
-            bool decide = false, open = false; f3 ro = splat3(0.0f), rd = splat3(0.0f);
-            if (owns && verdict) {                                                   // the closest hit of the ray that just ended (gi1_step, iteration > 0)
-                Hit h; h.t = hitTri < 0 ? -1.0f : tL; h.u = hu; h.v = hv; h.tri = hitTri;
-                const Payload hit = (h.tri < 0) ? make_miss() : make_hit(sc, o, d, h);
-                if (b == 0) { samplePoint = pos3(hit); sampleNormal = nrm3(hit); }
-                if (hit.hitDistance < 0.0f) Lo = Lo + T * st.sky;
-                else {
-                    const Mat m = load_mat(sc, tri_material(sc, hit.objectIndex));
-                    const f3 em = emission(m);
-                    if (length(em) > 0.0f) Lo = Lo + T * em;
-                    else {
-                        const f3 alb = sample_albedo(sc, m, hit.u, hit.v);
-                        float bpdf;
-                        const f3 bdir = sample_brdf(nrm3(hit), -d, alb, m.metallic, m.roughness, seed, bpdf);
-                        const f3 bbrdf = eval_brdf(nrm3(hit), -d, bdir, alb, m.metallic, m.roughness);
-                        const float bcos = gmax(dot(bdir, nrm3(hit)), 0.0f);
-                        T = T * ((bbrdf * bcos) / bpdf);
-                        ro = pos3(hit) + nrm3(hit) * 1e-12f; rd = bdir;
-                        ++b;
-                        open = b < (int)st.maxBounces;
-                    }
-                }
-                verdict = false; decide = true;
-            }
-            for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) {                                                     // lanes without a pixel take the next ones of the list
-                    const unsigned long long need = __ballot(!owns);
-                    if (more && need != 0ull) {
-                        if (chunkNext >= chunkEnd && hasDyn) {
-                            uint32_t base = 0;
-                            uint32_t size = (total - chunkEnd) / nWaves;
-                            size = size < q.minChunk ? q.minChunk : (size > chunk ? chunk : size);
-                            if (lane == 0u) base = dynBase + atomicAdd(q.head, size);
-                            base = (uint32_t)__shfl((int)base, 0);
-                            chunkNext = base < total ? base : total;
-                            chunkEnd = (base + size < total) ? base + size : total;
-                        }
-                        const uint32_t slot = chunkNext + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                        const uint32_t want = (uint32_t)__popcll(need), avail = chunkEnd - chunkNext;
-                        chunkNext += (want < avail) ? want : avail;
-                        more = chunkNext < chunkEnd || (hasDyn && chunkEnd < total);
-                        if (!owns && slot < chunkEnd) {                              // gi1_step, iteration 0: the first BRDF sample at the visible point
-                            i = q.list[slot];
-                            const uint32_t x = i % fr.W, y = i / fr.W;
-                            const Payload pp = fr.payload[i];
-                            seed = i * (fr.frameIndex + 1u + st.randSeed);
-                            const f3 pd = ray_direction(cam, x, y);
-                            const Mat hm = load_mat(sc, tri_material(sc, pp.objectIndex));
-                            const f3 albedo = sample_albedo(sc, hm, pp.u, pp.v);
-                            float pdf;
-                            const f3 dir = sample_brdf(nrm3(pp), -pd, albedo, hm.metallic, hm.roughness, seed, pdf);
-                            const f3 brdf = eval_brdf(nrm3(pp), -pd, dir, albedo, hm.metallic, hm.roughness);
-                            const float cosT = gmax(dot(dir, nrm3(pp)), 0.0f);
-                            T = splat3(1.0f); Lo = splat3(0.0f); samplePoint = splat3(0.0f); sampleNormal = splat3(0.0f); b = 0;
-                            T = T * ((brdf * cosT) / pdf);
-                            ro = pos3(pp) + nrm3(pp) * 1e-12f; rd = dir;
-                            open = st.maxBounces > 0u;
-                            owns = true; verdict = false; decide = true;
-                        }
-                    }
-                }
-                if (decide) {
-                    decide = false;
-                    if (open) {
-                        seed += (uint32_t)(31 * b);
-                        o = ro; d = rd;
-                        pk = make_raypk(o, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-                        hitTri = -1; hu = 0.0f; hv = 0.0f; tL = 3.402823466e+38f;
-                        cut = tL * 1.000001f;
-                        if (COUNT) { nBox = 0; nNode = 0; nTri = 0; }
-                        top = 0; lane_push(lds, top, kExit);
-                        cur = (sc.triCount == 0 || ray_not_finite(o, d)) ? kExit : sc.rootRef;
-                        tracing = true;
-                    } else {
-                        // the path is complete: initial reservoir (R.cu:2186-2228), temporal reuse (:2230-2290)
-                        const uint32_t y = i / fr.W;
-                        const Payload pp = fr.payload[i];
-                        const uint32_t originalSeed = i * (fr.frameIndex + 1u + st.randSeed);
-                        GIRes R; gi_reset(R);
-                        {
-                            GISample sm; sm.seed = originalSeed;
-                            sm.vp[0] = pp.px; sm.vp[1] = pp.py; sm.vp[2] = pp.pz;
-                            const f2 vn = oct_encode(nrm3(pp)); sm.vn[0] = vn.x; sm.vn[1] = vn.y;
-                            sm.sp[0] = samplePoint.x; sm.sp[1] = samplePoint.y; sm.sp[2] = samplePoint.z;
-                            const f2 sn = oct_encode(sampleNormal); sm.sn[0] = sn.x; sm.sn[1] = sn.y;
-                            sm.Lo[0] = Lo.x; sm.Lo[1] = Lo.y; sm.Lo[2] = Lo.z; sm.pdf = 0.0f;
-                            const float len = length(Lo);
-                            gi_update(R, sm, len, 1u, len, seed);
-                            R.W = R.s.pdf > 0.0f ? ((1.0f / R.s.pdf) * R.wSum) / (float)R.M : 0.0f;
-                        }
-                        if (st.useTemporal) {
-                            uint32_t prow;
-                            const uint32_t prevIdx = prev_pixel(cam, pos3(pp), prow);
-                            const f3 prevN = oct_decode(fr.normalPrev[prevIdx]);
-                            GIRes prev = fr.giPrev[prevIdx];
-                            const bool valid = (double)dot(prevN, nrm3(pp)) >= 0.99 && prow >= fr.histBegin && prow < fr.histEnd;
-                            const f3 plo = lo3(prev.s);
-                            if (valid && prev.M > 0u && dot(plo, plo) > 0.0f) {
-                                GIRes Tm = R;
-                                const uint32_t lim = st.historyLimit * R.M;
-                                prev.M = (lim < prev.M) ? lim : prev.M;
-                                const float pdf = length(plo);
-                                gi_update(Tm, prev.s, (pdf * prev.W) * (float)prev.M, prev.M, pdf, seed);
-                                Tm.W = Tm.s.pdf > 0.0f ? Tm.s.pdf / ((float)Tm.M * Tm.s.pdf) : 0.0f;
-                                gi_reset(R);
-                                gi_merge(R, Tm, Tm.s.pdf, seed);
-                            }
-                        }
-                        fr.gi[i] = R;
-                        {
-                            const f2 nn = oct_encode(nrm3(pp));
-                            float4* qh = fr.giHot + (size_t)i * 4;
-                            qh[0] = make_float4(pp.hitDistance, nn.x, nn.y, length(lo3(R.s)));
-                            qh[1] = make_float4(R.s.vp[0], R.s.vp[1], R.s.vp[2], __int_as_float((int)R.M));
-                            qh[2] = make_float4(R.s.sp[0], R.s.sp[1], R.s.sp[2], R.wSum);
-                            qh[3] = make_float4(R.s.sn[0], R.s.sn[1], 0.0f, 0.0f);
-                        }
-                        const bool toPart2 = (y >= fr.rowBegin && y < fr.rowEnd);
-                        const unsigned long long pm = __ballot(toPart2);
-                        if (pm != 0ull) {                                            // wave-level append to the Part-2 list
-                            const int leader = __ffsll((long long)pm) - 1;
-                            uint32_t base = 0;
-                            if ((int)lane == leader) base = atomicAdd(q.part2Count, (uint32_t)__popcll(pm));
-                            base = (uint32_t)__shfl((int)base, leader);
-                            if (toPart2) q.part2List[base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = i;
-                        }
-                        owns = false;
-                    }
-                }
-            }
-        }
-        if (__ballot(tracing) == 0ull) { if (!more && __ballot(owns) == 0ull) break; else continue; }
-        while (true) {
-            bool walk = tracing && cur >= 0;
-            while (walk) {
-                { Stack stk; stk.lds = lds; stk.top = top; cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, stk, nBox, nNode); top = stk.top; }
-                walk = cur >= 0;
-                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
-            }
-            if (tracing && cur < 0 && cur != kExit) {
-                const uint32_t code = (uint32_t)~cur, firstTri = code >> 2, cnt = (code & 3u) + 1u;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const float4* tp = sc.leafTris + (size_t)(firstTri + k) * 3;
-                    float t, u, v; uint32_t id;
-                    if (COUNT) nTri += 1;
-                    if (!tri_test(tp, o, d, t, u, v, id)) continue;
-                    if (t < tL) { hitTri = (int32_t)id; tL = t; cut = t * 1.000001f; hu = u; hv = v; }
-                }
-                cur = lane_pop(lds, top);
-            }
-            if (tracing && cur == kExit) {
-                if (COUNT) {
-                    atomicAdd(sc.rayCounter + 0, 1ull); atomicAdd(sc.rayCounter + 1, (unsigned long long)nBox);
-                    atomicAdd(sc.rayCounter + 2, (unsigned long long)nTri); atomicAdd(sc.rayCounter + 3, (unsigned long long)(hitTri < 0 ? 0 : 1));
-                    atomicAdd(sc.rayCounter + 4, (unsigned long long)nNode);
-                }
-                tracing = false; verdict = true;
-            }
-            const unsigned long long act = __ballot(tracing);
-            if (act == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(!tracing && (owns || more))) >= q.refillLanes) break;
-        }
-    }
-}
-
 // ============================================================ small scenes: the whole frame of techniques 0-5 in ONE launch
 // A scene whose rays cost a handful of node visits (Cornell box: 3; the reference's banana: 8) gains nothing from re-packing lanes
 // between bounces, and every one of the 2 x steps + 1 stage launches pays its own fill, drain and one-wave-round latency: the

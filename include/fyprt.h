@@ -296,14 +296,13 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 18: 1 (default) = a ReSTIR DI Part-2 shadow ray whose pixel is black in EVERY outcome (both candidate radiances exactly zero) is
  *        not traced; 0 = every Part-2 pixel traces its ray as Renderer.cu:2010-2031 does.  Same pixels; fewer rays are counted.
  *        Also on by default since r03: key 2 = 0 uses at most 4 workgroups per CU for the persistent ReSTIR DI grid while frames are pipelined.
- * key 19: 1 = ReSTIR GI Part 2 as ONE launch: a thread keeps its pixel for the whole neighbour loop (state in registers, the visibility ray
- *         traced in place) instead of 2 x neighbours + 1 stage launches with the state, ray and result records moving through memory; same
- *         pixels bit for bit, same ray counts.  2 = the same as one PERSISTENT launch: a lane owns a pixel, lanes without a ray in flight are
- *         serviced together (merge, next neighbour, next pixel from the list) like the persistent trace kernels' refill.  0 = the stages.
+ * key 19: ReSTIR GI Part 2.  2 (default) = ONE persistent launch (k_gi2_persistent): a lane owns a pixel of the Part-2 list for its whole neighbour
+ *         loop — reservoir state in registers, visibility rays traced in place — and the lanes of a wave that have no ray in flight are serviced
+ *         together (merge the verdict, next accepted neighbour, next pixel from the list), like the persistent trace kernels' refill.
+ *         0 = the stages (2 x neighbours + 1 launches; state, ray and result records move through memory).  1 = one launch, one thread per
+ *         pixel without refill (slower on a whole frame, kept for comparison).  Same pixels bit for bit, same ray counts in every mode.
  * key 20: k_gi2_persistent (key 19 = 2): lanes of a wave without a ray in flight before the wave services them together (default 48; 0 = default).
- * key 21: 1 = ReSTIR GI Part 1's bounce loop (after the primary kernel) as ONE persistent launch: a lane owns a pixel from its first BRDF sample to
- *         its reservoir, path state in registers, rays traced in place, lanes without a ray serviced together (threshold: key 20).  0 = the stages.
- * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 13, 18, 21: 0..1, keys 12, 14, 15, 17, 19: 0..2, key 2: 0..16, keys 5, 6, 7, 20: 0..64,
+ * Values are range-checked (FYPRT_EINVAL): key 0: 0..2, keys 1, 3, 11, 13, 18: 0..1, keys 12, 14, 15, 17, 19: 0..2, key 2: 0..16, keys 5, 6, 7, 20: 0..64,
  * key 8: 0..31, key 16: 0..1024; keys 19..23 are reserved (0). */
 int fyprt_set_tuning(fyprt_context* ctx, int key, int value);
 /* The value in effect (key 8: the budget actually used for the uploaded scene, which an instrumented restatement of the

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 SIZES = [(64, 48), (80, 40), (48, 64)]
 NEUTRAL_KEYS = {0: [0, 1, 2], 1: [0, 1], 2: [0, 1, 3], 3: [0, 1], 4: [0, 16, 128], 5: [0, 8, 48], 6: [0, 16], 7: [0, 16], 9: [0, 1, 4], 10: [0, 8], 11: [0, 1], 14: [0, 1, 2],
-                15: [0, 1, 2], 17: [0, 1, 2], 18: [0, 1]}       # r03: fused small-scene frame on / off, dead rays skipped / traced
+                15: [0, 1, 2], 17: [0, 1, 2], 18: [0, 1],       # r03: fused small-scene frame on / off, dead rays skipped / traced
+                19: [0, 1, 2], 20: [0, 8, 48]}                  # r03: ReSTIR GI Part 2 as stages, one launch, one persistent launch
 
 
 def _random_settings(rng):

@@ -90,13 +90,12 @@ def test_gi_part2_in_one_launch_equals_the_stages(scene_name, skip_dead):
     sc, W, H = mk_scene(), 136, 88                   # not a multiple of 16: partial tiles
     cam = mk_cam(W, H)
     outs = []
-    for mode, part1 in ((0, 0), (1, 0), (2, 0), (0, 1), (2, 1)):     # key 21 = 1: Part 1's bounce loop as one persistent launch too (k_gi1_persistent)
+    for mode in (0, 1, 2):
         ctx = capi.Context(0)
         ctx.resize(W, H)
         ctx.upload_scene(sc)
         ctx.set_camera(cam)
         ctx.set_tuning(19, mode)
-        ctx.set_tuning(21, part1)
         ctx.set_tuning(18, skip_dead)
         ctx.set_ray_counting(True)
         st = settings_for(capi.RESTIR_GI, light_bounces=2)
@@ -236,7 +235,7 @@ def test_light_sorted_tasks_with_pipelined_async_frames():
 
 def test_tuning_values_are_range_checked():
     ctx = capi.Context(0)
-    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (17, 3), (18, 2), (19, 3), (20, 65), (21, 2), (24, 0), (-1, 0)):
+    for key, bad in ((5, 65), (0, 3), (4, -1), (8, 32), (11, 2), (13, 2), (14, 3), (15, 3), (16, 1025), (17, 3), (18, 2), (19, 3), (20, 65), (24, 0), (-1, 0)):
         with pytest.raises(capi.FyprtError):
             ctx.set_tuning(key, bad)
     ctx.set_tuning(5, 64)
