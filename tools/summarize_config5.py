@@ -13,7 +13,6 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-FRAMES = 35          # bench_configs.py: 5 warm-up + 30 timed frames with the production kernels (the counting frame uses the <true> kernels)
 
 
 def short(name):
@@ -27,7 +26,9 @@ def main():
     stats = sorted(glob.glob(str(out / f"{prefix}_stats" / "*" / "*kernel_stats.csv")))
     assert stats, "no kernel_stats.csv"
     rows = {}
-    for r in csv.DictReader(open(stats[-1])):
+    raw = list(csv.DictReader(open(stats[-1])))
+    FRAMES = min(int(r["Calls"]) for r in raw if "k_gi_primary<false>" in r["Name"])      # one primary launch per production frame (the counting frame runs the <true> twins)
+    for r in raw:
         n = short(r["Name"])
         if "true" in n or n.startswith("__amd") or not (n.startswith("k_") or "Kernel" in n):
             continue
