@@ -90,7 +90,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, 1, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, /*19: ReSTIR GI Part 2 in one launch*/ 2, /*20: its service threshold*/ 48, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, /*9: static chunks, 0 = auto*/ 0, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, /*19: ReSTIR GI Part 2 in one launch*/ 2, /*20: its service threshold*/ 48, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;
@@ -844,7 +844,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
             TraceQueue q{};
             q.rays = io.raysOut; q.hits = c->wfHits[(it + 1u) & 1u].p; q.count = io.countOut; q.raysPer = r.raysPer; q.head = r.heads + it + 1;
             q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24);
-            q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
+            q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 2); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);      // (auto: two static chunks per wave — config 3 3.13 -> 3.08 ms, profiles/README.md r03)
             // small trees (cheap rays): one thread per ray; big ones: persistent waves with lane refill (tuning key 15: 0 = by tree size)
             const bool simple = c->tuning[15] == 2 || (c->tuning[15] == 0 && c->hostBvh.tris.size() < 65536u);
             if (simple) {
