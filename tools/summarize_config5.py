@@ -5,6 +5,7 @@ Per kernel: launches per frame, mean duration, time per frame, HBM bytes per lau
 gfx950 correction of MI355X_MICROARCH.md §HBM for 16-byte-per-lane loads) and the rate that is.  The instrumented twins (<true>) of the
 one counting frame are left out."""
 import csv
+import os
 import glob
 import json
 import re
@@ -23,7 +24,7 @@ def short(name):
 def main():
     prefix, rnd = sys.argv[1], sys.argv[2]
     out = ROOT / "gpurun_out"
-    stats = sorted(glob.glob(str(out / f"{prefix}_stats" / "*" / "*kernel_stats.csv")))
+    stats = sorted(glob.glob(str(out / f"{prefix}_stats" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
     assert stats, "no kernel_stats.csv"
     rows = {}
     raw = list(csv.DictReader(open(stats[-1])))
@@ -35,7 +36,7 @@ def main():
         rows[n] = {"launches_per_frame": round(int(r["Calls"]) / FRAMES, 2), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
                    "ms_per_frame": round(float(r["TotalDurationNs"]) / 1e6 / FRAMES, 4)}
     for tag in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(str(out / f"{prefix}_{tag}" / "*" / "*counter_collection.csv")))
+        files = sorted(glob.glob(str(out / f"{prefix}_{tag}" / "*" / "*counter_collection.csv")), key=os.path.getmtime)
         acc, cnt = defaultdict(float), defaultdict(int)
         for r in csv.DictReader(open(files[-1])) if files else []:
             n = short(r["Kernel_Name"])

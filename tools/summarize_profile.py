@@ -22,6 +22,23 @@ def kname(s):
     return re.sub(r"<[^>]*>", "", s.split("(")[0].replace("void ", "").replace("rt::", "")).strip()
 
 
+def newest_run_only(pass_dir):
+    """gpurun merges every call's files into the same local directories: keep the files of the newest profiler process only"""
+    import os
+    import re
+    by_pid = collections.defaultdict(list)
+    for f in glob.glob(str(pass_dir / "**" / "*.csv"), recursive=True):
+        m = re.match(r"(\d+)_", os.path.basename(f))
+        if m:
+            by_pid[m.group(1)].append(f)
+    if len(by_pid) > 1:
+        newest = max(by_pid, key=lambda p: max(os.path.getmtime(f) for f in by_pid[p]))
+        for p, fs in by_pid.items():
+            if p != newest:
+                for f in fs:
+                    os.remove(f)
+
+
 def main():
     from bench import kernel_source_sha
     prefix, rnd = sys.argv[1], sys.argv[2]
@@ -29,6 +46,9 @@ def main():
     out_dir.mkdir(parents=True, exist_ok=True)
     g = ROOT / "gpurun_out"
     tag = "restir_di_1080p_hall1M"
+    for d in g.glob(f"{prefix}_*"):
+        if d.is_dir():
+            newest_run_only(d)
     shutil.copy(glob.glob(str(g / f"{prefix}_stats/**/*_kernel_stats.csv"), recursive=True)[0], out_dir / f"{tag}_kernel_stats.csv")
     shutil.copy(g / f"{prefix}_bench.json", out_dir / f"{tag}_bench_under_rocprof.json")
     bench = json.loads((g / f"{prefix}_bench.json").read_text())
