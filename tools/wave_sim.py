@@ -192,6 +192,46 @@ def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, gree
     return w.cycles, w.lane_cycles
 
 
+def run_workgroup_repack(E, first, count, repack_cost=0, refill_rays=96, lanes=256):
+    """Upper bound for RE-PACKING rays between the four waves of a workgroup every round: the workgroup's 256 rays are dealt to its waves by
+    the kind of work they want, so a node round runs in ceil(n / 64) full waves and a triangle round in ceil(t / 64); `repack_cost` = issue
+    cycles every wave pays per round for moving ray state through LDS.  Returns (issue cycles summed over the waves, lane cycles)."""
+    task = np.full(lanes, -1, dtype=np.int64); pos = np.zeros(lanes, dtype=np.int64); tri = np.zeros(lanes, dtype=np.int64)
+    nxt, end = first, first + count
+    cyc = lane_cyc = 0
+    while True:
+        idle = np.flatnonzero(task < 0)
+        if nxt < end and (len(idle) >= refill_rays or len(idle) == lanes):
+            got = min(len(idle), end - nxt)
+            task[idle[:got]] = np.arange(nxt, nxt + got); pos[idle[:got]] = 0; tri[idle[:got]] = 0
+            nxt += got
+            w = -(-got // 64)
+            cyc += C_REFILL * w; lane_cyc += C_REFILL * got
+        act = task >= 0
+        if not act.any():
+            if nxt >= end:
+                break
+            continue
+        # settle: enter leaves, retire finished rays
+        while True:
+            e = np.where(act, E[np.maximum(task, 0), pos], -1)
+            at = act & (tri == 0) & (e >= 100)
+            if not at.any():
+                break
+            tri = np.where(at, e - 100, tri); pos = np.where(at, pos + 1, pos)
+        e = np.where(act, E[np.maximum(task, 0), pos], -1)
+        done = act & (tri == 0) & (e < 0)
+        task = np.where(done, -1, task); act = task >= 0
+        n = act & (tri == 0) & (e == 0); t = act & (tri > 0)
+        nn, nt = int(n.sum()), int(t.sum())
+        if nn == 0 and nt == 0:
+            continue
+        wn, wt = -(-nn // 64), -(-nt // 64)
+        cyc += wn * (C_NODE + repack_cost) + wt * (C_TRI + repack_cost); lane_cyc += nn * C_NODE + nt * C_TRI
+        pos = np.where(n, pos + 1, pos); tri = np.where(t, tri - 1, tri)
+    return cyc, lane_cyc
+
+
 def main():
     W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 144)
     cache = Path(f"/tmp/wave_sim_events2_{W}x{H}.npz")
@@ -272,6 +312,16 @@ def main():
             cyc += c; lane += l; opt += c2
         nr = nwaves * per
         print(json.dumps({"policy": name, "issue_cycles_per_ray_if_no_ray_walked_in_vain": round(opt / nr, 1), "issue_cycles_per_ray": round(cyc / nr, 1), "lane_utilisation": round(lane / (cyc * 64), 3), "rays": nr}), flush=True)
+    for cost in (0, 100, 200, 300):
+        cyc = lane = 0
+        nwg = nwaves // 4
+        perwg = (len(shadow) // nwg // chunk) * chunk
+        for g in range(nwg):
+            c, l = run_workgroup_repack(E, g * perwg, perwg, repack_cost=cost)
+            cyc += c; lane += l
+        nr = nwg * perwg
+        print(json.dumps({"policy": f"rays re-packed between the 4 waves of a workgroup every round (upper bound), + {cost} issue cycles per wave and round for the move",
+                          "issue_cycles_per_ray": round(cyc / nr, 1), "lane_utilisation": round(lane / (cyc * 64), 3), "rays": nr}), flush=True)
     for name, kw in policies[:1]:
         t0 = time.time()
         cyc = lane = 0
