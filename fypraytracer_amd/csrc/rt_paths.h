@@ -34,6 +34,7 @@ struct PathIO {
     uint32_t* misList; uint32_t* misCount;                                    // NEE: paths whose BRDF ray hit an emitter
     const uint32_t* ownersIn; uint32_t* ownersOut;                            // ReSTIR GI Part 2: the entries' pixels as a list of their own (its steps do not read the ray records)
     uint32_t fusedOwner;                                                      // k_path_fused: the thread's own pixel (step 0 has no list to read it from); kNotFused otherwise
+    float4* local;                                                            // k_path_fused (LOCAL instantiations of the step functions): the thread's own state (2 quads), ray (3) and hit (1) — registers, not memory
 };
 constexpr uint32_t kNotFused = 0xFFFFFFFFu;
 
@@ -110,10 +111,11 @@ RT_DEV uint32_t owner_of(const PathIO& io, uint32_t j) {
 
 // ============================================================ techniques 0-4 (Renderer.cu:565-1284): sample loop x bounce loop
 // state: S0 = throughput, seed | S1 = radiance, sample | bounce << 16
-template <int TECH>
+// LOCAL (k_path_fused): state, ray and hit of the previous step are the thread's own six quads (PathIO::local) instead of records in memory
+template <int TECH, bool LOCAL = false>
 RT_DEV bool path_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
     const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
-    float4* S = io.state + (size_t)i * io.stateStride;
+    float4* S = LOCAL ? io.local : io.state + (size_t)i * io.stateStride;
     const int nSamples = (TECH == T_BRUTE) ? 1 : (int)st.sampleCount;
     uint32_t seed; int s = 0, b = 0; f3 T = splat3(1.0f), radiance = splat3(0.0f), ro = splat3(0.0f), rd = splat3(0.0f);
     bool open = false;                                                     // a sample's path is in flight and needs its next ray
@@ -122,9 +124,9 @@ RT_DEV bool path_step(const DevScene& sc, const DevCamera& cam, const DevFrame& 
         const float4 s0 = S[0], s1 = S[1];
         T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); radiance = xyz(s1);
         const uint32_t sb = (uint32_t)__float_as_int(s1.w); s = (int)(sb & 0xFFFFu); b = (int)(sb >> 16);
-        const float4* R = io.raysIn + (size_t)j * 3;
+        const float4* R = LOCAL ? io.local + 2 : io.raysIn + (size_t)j * 3;
         ro = xyz(R[0]); rd = xyz(R[1]);
-        const Hit h = load_hit(io.hitsIn, j);
+        const Hit h = LOCAL ? load_hit(io.local, 5u) : load_hit(io.hitsIn, j);
         if (h.tri < 0) radiance = radiance + T * st.sky;
         else {
             const Payload hit = make_hit(sc, ro, rd, h);
@@ -178,16 +180,17 @@ RT_DEV bool path_step(const DevScene& sc, const DevCamera& cam, const DevFrame& 
 
 // ============================================================ LIGHT_SOURCE_SAMPLING (Renderer.cu:1287-1408): one shadow ray per sample
 // state: S0 = pending contribution T, seed | S1 = radiance, sample
+template <bool LOCAL = false>
 RT_DEV bool light_step(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevSettings& st, const PathIO& io, uint32_t j, RayRec& out) {
     const uint32_t i = owner_of(io, j), x = i % fr.W, y = i / fr.W;
-    float4* S = io.state + (size_t)i * io.stateStride;
+    float4* S = LOCAL ? io.local : io.state + (size_t)i * io.stateStride;
     uint32_t seed; int s = 0; f3 radiance = splat3(0.0f);
     if (io.iteration == 0u) seed = i * fr.frameIndex;
     else {
         const float4 s0 = S[0], s1 = S[1];
         const f3 T = xyz(s0); seed = (uint32_t)__float_as_int(s0.w); radiance = xyz(s1); s = __float_as_int(s1.w);
-        const uint32_t lightTri = (uint32_t)__float_as_int(io.raysIn[(size_t)j * 3 + 1].w);
-        const float4 hq = io.hitsIn[j];
+        const uint32_t lightTri = (uint32_t)__float_as_int(LOCAL ? io.local[3].w : io.raysIn[(size_t)j * 3 + 1].w);
+        const float4 hq = LOCAL ? io.local[5] : io.hitsIn[j];
         if (hq.x < 0.0f) radiance = radiance + T * st.sky;
         else if ((uint32_t)__float_as_int(hq.w) == lightTri) {
             const Mat lm = load_mat(sc, __float_as_int(sc.triPos[(size_t)lightTri * 3].w));
@@ -862,9 +865,9 @@ __global__ __launch_bounds__(kBlock) RT_GI2_WAVES void k_gi2_persistent(DevScene
 // Cornell frame of BASELINE config 1 took 0.21 ms in ten launches against 0.11 ms for one thread per pixel.  This
 // kernel is that one thread per pixel again — primary ray, then the SAME step functions (path_step / light_step: same expressions, same
 // random draws, same order of additions) with the same one-thread-per-ray traversal (trace_one) in between — so its pixels are the stage
-// path's bit for bit (tests/test_gpu_tuning.py).  The step functions keep their state where the stages keep it (PathIO::state, the ray
-// and hit records at the thread's own slot): a thread reads back what it has written itself.  Chosen by the host for trees of fewer
-// than 64 k triangles (tuning key 17).
+// path's bit for bit (tests/test_gpu_tuning.py).  The step functions are instantiated with LOCAL = true: what a stage keeps in the state,
+// ray and hit records between two steps is the thread's own six quads here (PathIO::local — registers; the first version wrote and re-read the
+// records at the thread's own slot, 8 % of the Cornell frame).  Chosen by the host for trees of fewer than 64 k triangles (tuning key 17).
 template <int TECH, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_path_fused(DevScene sc, DevCamera cam, DevFrame fr, DevSettings st, PathIO io, uint32_t steps) {
     extern __shared__ int32_t s_stack[];                         // (stackBudget + 1) entries x kBlock threads, sized at launch
@@ -889,15 +892,15 @@ __global__ __launch_bounds__(kBlock) void k_path_fused(DevScene sc, DevCamera ca
         }
     }
     io.fusedOwner = i;
+    float4 own[6];                                               // the thread's own state (2), ray (3), hit (1): PathIO::local — constant indices, so registers
+    io.local = own;
     for (uint32_t it = 0; live && it <= steps; ++it) {
         io.iteration = it;
         RayRec r;
-        live = (TECH == T_LIGHT) ? light_step(sc, cam, fr, st, io, j, r) : path_step<(TECH <= T_BRDF ? TECH : T_BRUTE)>(sc, cam, fr, st, io, j, r);
+        live = (TECH == T_LIGHT) ? light_step<true>(sc, cam, fr, st, io, j, r) : path_step<(TECH <= T_BRDF ? TECH : T_BRUTE), true>(sc, cam, fr, st, io, j, r);
         if (!live) break;
-        store_ray(io.raysOut, j, r);
-        const float4 h = trace_one<COUNT>(sc, xyz(r.q0), xyz(r.q1), (uint32_t)__float_as_int(r.q1.w), r.q2.x, r.q2.y, s_stack + threadIdx.x);
-        const_cast<float4*>(io.hitsIn)[j] = h;
-        __threadfence_block();                                   // the thread's own stores are complete before the next step loads them
+        own[2] = r.q0; own[3] = r.q1; own[4] = r.q2;
+        own[5] = trace_one<COUNT>(sc, xyz(r.q0), xyz(r.q1), (uint32_t)__float_as_int(r.q1.w), r.q2.x, r.q2.y, s_stack + threadIdx.x);
     }
 }
 
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(kBlock) RT_SHADE_WAVES void k_shade(DevScene sc, De
         bool live = false, toPart2 = false;
         RayRec r0; uint32_t owner = 0;
         if (j < count) {
-            if (TECH == T_LIGHT) live = light_step(sc, cam, fr, st, io, j, r0);
+            if (TECH == T_LIGHT) live = light_step<false>(sc, cam, fr, st, io, j, r0);
             else if (TECH == T_NEE) { const int k = nee_consume(sc, cam, fr, st, io, j, owner); live = k == 1; toPart2 = k == 2; }
             else if (TECH == T_GI1) live = gi1_step(sc, cam, fr, st, io, j, r0, toPart2);
             else if (TECH == T_GI2) live = gi2_step(sc, cam, fr, st, io, j, r0);

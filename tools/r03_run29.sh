@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/r03
+V=fypraytracer_amd/csrc/variants
+timeout -k 10 400 python -m pytest tests/test_gpu_tuning.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -n 2
+t() { echo "$1 cfg$3: $(FYPRT_LIB=${2:-fypraytracer_amd/csrc/libfyprt.so} timeout -k 10 120 python tools/bench_configs.py $3 2>/dev/null | grep -o '"kernel_ms_per_frame": [0-9.]*')"; }
+for rep in 1 2 3; do
+for c in 1 2; do
+t base $V/libfyprt_base4.so $c
+t new "" $c
+done
+done
