@@ -90,7 +90,7 @@ struct fyprt_context {
     size_t queueStride = 0;                     // float4s per task queue
     size_t sortGroups = 0;                      // setup workgroups the sort scratch is sized for (per parity)
     int traceOcc = 0; size_t traceOccLds = 0;   // cached residency of the persistent trace kernel
-    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, 0, 0, /*9: static chunks, 0 = auto*/ 0, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, /*19: ReSTIR GI Part 2 in one launch*/ 2, /*20: its service threshold*/ 48, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
+    int tuning[24] = {2, 1, 0, 0, 128, 24, 24, /*7: node-loop quorum of the primary-ray kernels*/ 32, 0, /*9: static chunks, 0 = auto*/ 0, 32, 1, 0, 0, 0, 0, /*16: top nodes kept in LDS*/ 0, /*17: fused small-scene frame*/ 0, /*18: skip dead shadow rays*/ 1, /*19: ReSTIR GI Part 2 in one launch*/ 2, /*20: its service threshold*/ 48, 0, 0, 0};   // [0] tile order  [1] DI part 2: 0 one thread per pixel, 1 wavefront queue + persistent trace  [2] persistent workgroups per CU
     int numCUs = 256;
     // wavefront path engine (rt_paths.h): two ray lists + results (ping-pong), per-pixel path state, pixel lists, list counters
     DevBuf<float4> wfRays[2], wfHits[2], wfState; DevBuf<uint32_t> wfPixels, wfPixels2, wfCounters;

@@ -262,8 +262,8 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
  * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
  *        fewer than this many lanes are still walking inner nodes (default 24; 0 = classic while-while).
- * key 7: the same for every other kernel (default 0 = 16 for the light-source / NEE kernels, none elsewhere: measured
- *        neutral or slightly negative there).
+ * key 7: the same for the kernels that trace primary rays (k_primary, k_gi_primary, ReSTIR DI Part 1, the fused small-scene frame):
+ *        default 32 since r03 (bench frame 0.843 -> 0.82-0.83 ms, config 3 3.09 -> 3.03 ms; it was neutral before the node visit was trimmed); 0 = never.
  * key 8: pending-entry budget of the traversal stack rule (default 0 = a few entries above the tree's level count, chosen
  *        so that one more workgroup fits a CU's LDS; at most 31; always clamped from below to the tree's level count):
  *        siblings are pushed one by one while pending + 2 + levels(node) <= budget, else as one resume entry; the LDS stack holds budget + 1 entries per thread.
