@@ -150,7 +150,7 @@ class Wave:
         self.cycles += C_REFILL; self.lane_cycles += C_REFILL * min(64, got)
 
 
-def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, greedy=False, tri_weight=1.0, select_cost=0, select_cost_tri=None, postpone=0):
+def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, greedy=False, tri_weight=1.0, select_cost=0, select_cost_tri=None, postpone=0, leaf_quorum=0):
     """the persistent kernel's loop (rt_wavefront.h) on one wave; greedy: every round is the kind with the larger (lanes / cost)"""
     w = Wave(E, first, count, slots, postpone)
     while True:
@@ -184,6 +184,8 @@ def run_kernel_policy(E, first, count, quorum=24, refill_lanes=24, slots=1, gree
                     while t.any():                               # leaf phase: every lane at a leaf tests all its triangles
                         w.tri_round(t)
                         n, t = w.want()
+                        if leaf_quorum and int(t.any(axis=1).sum()) < leaf_quorum:
+                            break                                # leaf quorum: the few lanes with triangles left keep them for the next leaf phase
             w.settle()
             if not (w.task >= 0).any():
                 break
@@ -312,6 +314,14 @@ def main():
             cyc += c; lane += l; opt += c2
         nr = nwaves * per
         print(json.dumps({"policy": name, "issue_cycles_per_ray_if_no_ray_walked_in_vain": round(opt / nr, 1), "issue_cycles_per_ray": round(cyc / nr, 1), "lane_utilisation": round(lane / (cyc * 64), 3), "rays": nr}), flush=True)
+    for lq in (4, 8, 12, 16, 24):
+        cyc = lane = 0
+        for wv in range(nwaves):
+            c, l = run_kernel_policy(E, wv * per, per, quorum=24, refill_lanes=24, leaf_quorum=lq)
+            cyc += c; lane += l
+        nr = nwaves * per
+        print(json.dumps({"policy": f"kernel q24 r24 + leaf quorum {lq} (the leaf loop ends when fewer lanes than this still have triangles; they keep them for the next leaf phase)",
+                          "issue_cycles_per_ray": round(cyc / nr, 1), "lane_utilisation": round(lane / (cyc * 64), 3)}), flush=True)
     for cost in (0, 100, 200, 300):
         cyc = lane = 0
         nwg = nwaves // 4
