@@ -947,7 +947,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
                     GI2Queue gq{};
                     gq.list = c->wfPixels2.p; gq.count = cnt2; gq.head = cnt2 + L2 + 1;
                     gq.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); gq.refillLanes = (uint32_t)(c->tuning[20] > 0 ? c->tuning[20] : 48);
-                    gq.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); gq.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : gq.chunk);
+                    gq.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 2); gq.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : gq.chunk);
                     if (c->countRays) hipLaunchKernelGGL(k_gi2_persistent<true>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, c->dcam, fr, st, gq);
                     else hipLaunchKernelGGL(k_gi2_persistent<false>, dim3((uint32_t)(c->numCUs * perCU)), block, ldsBytes, c->stream, tsc, c->dcam, fr, st, gq);
                     HIPCHK(c, hipGetLastError());
@@ -981,7 +981,7 @@ static int enqueue_frame_impl(fyprt_context* c, const fyprt_settings* s, bool ti
             if (tech == FYPRT_RESTIR_DI && c->tuning[1] == 1) {
                 ShadowQueue q{};
                 q.tasks = c->shadowTasks.p + (size_t)par * c->queueStride; q.counters = c->queueCounters.p + 4 * par;
-                q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24); q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 1); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
+                q.chunk = (uint32_t)(c->tuning[4] > 0 ? c->tuning[4] : 128); q.refillLanes = (uint32_t)(c->tuning[5] > 0 ? c->tuning[5] : 24); q.staticChunks = (uint32_t)(c->tuning[9] > 0 ? c->tuning[9] : 2); q.minChunk = (uint32_t)(c->tuning[10] > 0 ? c->tuning[10] : q.chunk);
                 const size_t sg = (size_t)par * c->sortGroups;
                 q.sortMode = c->tuning[3] ? 1u : 0u; q.numGroups = grid.x; q.counts = c->sortCounts.p + sg; q.keys = c->sortKeys.p + sg * 256u; q.hist = c->sortHist.p + sg * kSortBins;
                 q.binOffset = c->sortOffset.p + sg * kSortBins; q.binTotal = c->sortTotal.p + (size_t)par * kSortBins; q.sorted = c->sortIndex.p + sg * 256u;

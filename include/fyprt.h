@@ -268,8 +268,8 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        so that one more workgroup fits a CU's LDS; at most 31; always clamped from below to the tree's level count):
  *        siblings are pushed one by one while pending + 2 + levels(node) <= budget, else as one resume entry; the LDS stack holds budget + 1 entries per thread.
  *        Unlike keys 0-7 the value can change the visiting order (exact-t ties may resolve differently).
- * key 9: chunks every persistent wave owns statically before it starts stealing from the shared head (default 0 = auto: 1 for the ReSTIR
- *        queues, 2 for the path engine's ray queues; on queues shorter than the grid the static part is an even share and no atomic is issued at all).
+ * key 9: chunks every persistent wave owns statically before it starts stealing from the shared head (default 0 = auto: 2 — r03: bench frame
+ *        0.833 -> 0.820 ms, config 3 3.13 -> 3.08 ms against 1; on queues shorter than the grid the static part is an even share and no atomic is issued at all).
  * key 10: smallest chunk of the guided self-scheduling of the shared part: claims shrink from key 4 towards this value as
  *        the queue runs out (default 32).
  * key 11: 1 (default) = wavefront ReSTIR DI frames are pipelined over two streams: Part 1 + setup of frame N+1 run beside the
