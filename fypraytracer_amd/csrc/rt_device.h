@@ -302,6 +302,10 @@ RT_DEV float light_tri_distance(const DevScene& sc, uint32_t tri, f3 o, f3 d) {
 // Closest hit over the acceleration structure (ONE tree: the reference's TLAS and per-mesh BLAS trees are merged at build).
 // Ordered traversal (nearest hit child first, the others pushed far-to-near), boxes culled against closest * 1.000001f; a
 // triangle is accepted when 1e-4 < t < closest, no back-face culling.
+// The node-loop quorum is given for a full wave; a wave in which only some lanes still have a ray (a thread-per-ray kernel late in its life, a
+// persistent wave before its refill) scales it to those lanes — with a fixed count such a wave would leave the loop after every single visit.
+RT_DEV uint32_t quorum_of(uint32_t q, uint32_t lanesWithRay) { return (q * lanesWithRay + 63u) >> 6; }
+
 template <bool COUNT>
 RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase, const float4* top4 = nullptr) {
     Hit h; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.tri = -1;
@@ -313,12 +317,13 @@ RT_DEV Hit trace_closest(const DevScene& sc, f3 o, f3 d, int32_t* ldsBase, const
     int32_t cur = sc.rootRef;
     while (true) {
         bool walk = cur >= 0;                           // (one compare per round serves the loop condition and the quorum ballot)
+        const uint32_t quorum = quorum_of(sc.nodeQuorum, (uint32_t)__popcll(__ballot(true)));     // lanes still in this loop = lanes with a ray
         while (walk) {
             cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, closestInfl, st, nBox, nNode);
             // lanes that reached a leaf wait outside this loop; once only a few lanes are still walking inner nodes,
             // stop and let everybody test their leaves (keeps SIMD lanes busy; pure scheduling, results unchanged)
             walk = cur >= 0;
-            if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
+            if ((uint32_t)__popcll(__ballot(walk)) < quorum) break;
         }
         if (cur >= 0) continue;
         if (cur == kExit) break;
@@ -366,10 +371,11 @@ RT_DEV ShadowHit trace_shadow(const DevScene& sc, f3 o, f3 d, uint32_t lightTri,
     bool occluded = false;
     while (!occluded) {
         bool walk = cur >= 0;
+        const uint32_t quorum = quorum_of(sc.nodeQuorum, (uint32_t)__popcll(__ballot(true)));
         while (walk) {
             cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode);
             walk = cur >= 0;
-            if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
+            if ((uint32_t)__popcll(__ballot(walk)) < quorum) break;
         }
         if (cur >= 0) continue;
         if (cur == kExit) break;

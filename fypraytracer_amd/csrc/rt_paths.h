@@ -825,10 +825,11 @@ __global__ __launch_bounds__(kBlock) RT_GI2_WAVES void k_gi2_persistent(DevScene
         if (__ballot(tracing) == 0ull) { if (!more && __ballot(owns) == 0ull) break; else continue; }
         while (true) {
             bool walk = tracing && cur >= 0;
+            const uint32_t quorum = quorum_of(sc.nodeQuorum, (uint32_t)__popcll(__ballot(tracing)));
             while (walk) {
                 { Stack stk; stk.lds = lds; stk.top = top; cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, stk, nBox, nNode); top = stk.top; }
                 walk = cur >= 0;
-                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
+                if ((uint32_t)__popcll(__ballot(walk)) < quorum) break;
             }
             if (tracing && cur < 0 && cur != kExit) {
                 const uint32_t code = (uint32_t)~cur, firstTri = code >> 2, cnt = (code & 3u) + 1u;

@@ -392,10 +392,11 @@ RT_DEV void di_part2_trace_body(const DevScene& sc, const DevFrame& fr, const Sh
         while (true) {
             // inner nodes
             bool walk = active && r.cur >= 0;                  // (one compare per round serves the loop condition and the quorum ballot)
+            const uint32_t quorum = quorum_of(sc.nodeQuorum, (uint32_t)__popcll(__ballot(active)));
             while (walk) {
                 { Stack st; st.lds = lds; st.top = r.top; st.top4 = top4; st.topCount = sc.topCount; r.cur = node_step<COUNT>(sc.nodes, sc.stackBudget, r.cur, r.pk, r.cut, st, r.nBox, r.nNode); r.top = st.top; }
                 walk = r.cur >= 0;
-                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
+                if ((uint32_t)__popcll(__ballot(walk)) < quorum) break;
             }
             // leaves
             if (active && r.cur < 0 && r.cur != kExit) {
@@ -537,10 +538,11 @@ RT_DEV void trace_rays_body(const DevScene& sc, const TraceQueue& q, int32_t* s_
         if (__ballot(active) == 0ull) { if (!more) break; else continue; }
         while (true) {
             bool walk = active && cur >= 0;
+            const uint32_t quorum = quorum_of(sc.nodeQuorum, (uint32_t)__popcll(__ballot(active)));
             while (walk) {
                 { Stack st; st.lds = lds; st.top = top; cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode); top = st.top; }
                 walk = cur >= 0;
-                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
+                if ((uint32_t)__popcll(__ballot(walk)) < quorum) break;
             }
             if (active && cur < 0 && cur != kExit) {
                 const uint32_t code = (uint32_t)~cur, firstTri = code >> 2, cnt = (code & 3u) + 1u;
@@ -599,10 +601,11 @@ RT_DEV float4 trace_one(const DevScene& sc, f3 o, f3 d, uint32_t mode, float a0,
         bool done = false;
         while (!done) {
             bool walk = cur >= 0;
+            const uint32_t quorum = quorum_of(sc.nodeQuorum, (uint32_t)__popcll(__ballot(true)));
             while (walk) {
                 cur = node_step<COUNT>(sc.nodes, sc.stackBudget, cur, pk, cut, st, nBox, nNode);
                 walk = cur >= 0;
-                if ((uint32_t)__popcll(__ballot(walk)) < sc.nodeQuorum) break;
+                if ((uint32_t)__popcll(__ballot(walk)) < quorum) break;
             }
             if (cur >= 0) continue;
             if (cur == kExit) break;

@@ -260,8 +260,9 @@ int fyprt_set_ray_counting(fyprt_context* ctx, int enabled);
  *        dominated by the geometry around the ray ORIGIN, which the unsorted tile order already keeps coherent.
  * key 4: tasks a persistent wave claims per queue-head atomic (default 128).
  * key 5: idle lanes that trigger a refill of a persistent wave (default 24).
- * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels: lanes waiting at a leaf are served once
- *        fewer than this many lanes are still walking inner nodes (default 24; 0 = classic while-while).
+ * key 6: inner-node loop quorum of the ReSTIR DI Part-2 shadow-ray kernels and the path engine's ray kernels: lanes waiting at a leaf are
+ *        served once fewer than this many lanes are still walking inner nodes (default 24; 0 = classic while-while).  The count is for a full
+ *        wave; r03: a wave in which only some lanes still have a ray scales it to those lanes (rt_device.h: quorum_of).
  * key 7: the same for the kernels that trace primary rays (k_primary, k_gi_primary, ReSTIR DI Part 1, the fused small-scene frame):
  *        default 32 since r03 (bench frame 0.843 -> 0.82-0.83 ms, config 3 3.09 -> 3.03 ms; it was neutral before the node visit was trimmed); 0 = never.
  * key 8: pending-entry budget of the traversal stack rule (default 0 = a few entries above the tree's level count, chosen
