@@ -81,7 +81,12 @@ RT_DEV f3 sample_dir(f3 n, f3 V, const Mat& m, f3 albedo, float ggxRoughness, ui
 //  * The cone axis normalize(centroid - p) and the direction normalize(p - centroid) of the importance are each other's exact
 //    negation (x - y == -(y - x), squares and the reciprocal square root are the same numbers), and d2 is the squared length the
 //    normalisation computes anyway: one normalisation instead of two, every value bitwise what the reference computes.
-RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
+// FLAT: the cluster's box has no extent along this axis (0 / 1 / 2; -1: none known) for EVERY lane of the wave — lights on a ceiling or a wall: the
+// four corners that differ from the other four in that coordinate only are the same four points, their terms the same values, and a minimum does
+// not care how often it sees a value: they are skipped (r03; the same bits, two thirds of the work — tests: every NEE / light-sampling parity test).
+template <int FLAT>
+RT_DEV float cluster_importance_t(f3 spPos, const DevLTNode& c) {
+#define RT_CORNER_SKIPPED(k) (FLAT >= 0 && ((k) & (4 >> FLAT)) != 0)
     // nine reciprocal lengths — the centroid's and the eight corners' — are the bulk of the work.  They go through rt_math.h's lean
     // correctly rounded 1/sqrt (13 instructions instead of 27), guarded ONCE for the nine arguments with a wave-uniform branch, so
     // the nine chains still interleave (a guard per call serialises them: measured, −5 % instead of −20 % on the pick kernel).
@@ -90,21 +95,22 @@ RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
     f3 v[8]; float d[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        if (RT_CORNER_SKIPPED(k)) continue;
         v[k] = mk3((k & 4) ? c.hi[0] : c.lo[0], (k & 2) ? c.hi[1] : c.lo[1], (k & 1) ? c.hi[2] : c.lo[2]) - spPos;
         d[k] = dot(v[k], v[k]);
     }
     uint32_t lo = __float_as_uint(dd), hi = lo;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const uint32_t b = __float_as_uint(d[k]); lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+    for (int k = 0; k < 8; ++k) { if (RT_CORNER_SKIPPED(k)) continue; const uint32_t b = __float_as_uint(d[k]); lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
     float inv, invk[8];
     if (__ballot(!(lean_range(__uint_as_float(lo)) && lean_range(__uint_as_float(hi)))) == 0ull) {
         inv = lean_rcp(lean_sqrt(dd));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) invk[k] = lean_rcp(lean_sqrt(d[k]));
+        for (int k = 0; k < 8; ++k) { if (RT_CORNER_SKIPPED(k)) continue; invk[k] = lean_rcp(lean_sqrt(d[k])); }
     } else {
         inv = 1.0f / __builtin_sqrtf(dd);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) invk[k] = 1.0f / __builtin_sqrtf(d[k]);
+        for (int k = 0; k < 8; ++k) { if (RT_CORNER_SKIPPED(k)) continue; invk[k] = 1.0f / __builtin_sqrtf(d[k]); }
     }
     const f3 axis = toC * inv;                                  // == normalize(centroid - p)
     // min over k of clamp(dot_k, -1, 1), starting from 1 — evaluated as clamp(min(1, dot_0, ..., dot_7), -1, 1): clamping is monotonic
@@ -112,7 +118,7 @@ RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
     // skips the NaN its clamp would have been; so the result is the same bits with one clamp instead of eight.
     float minDot = 1.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) minDot = __builtin_fminf(minDot, dot(axis, v[k] * invk[k]));      // v * inv == normalize(corner - p)
+    for (int k = 0; k < 8; ++k) { if (RT_CORNER_SKIPPED(k)) continue; minDot = __builtin_fminf(minDot, dot(axis, v[k] * invk[k])); }      // v * inv == normalize(corner - p)
     minDot = gclamp(minDot, -1.0f, 1.0f);
     const float theta_u = acos_f(minDot);
     const float d2 = __builtin_fmaxf(dd, 1e-12f);               // == dot(p - centroid, p - centroid)
@@ -121,6 +127,15 @@ RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
     const float theta = acos_f(dotVal);
     const float angleTerm = gclamp((theta - c.theta_o) - theta_u, 0.0f, c.theta_e);
     return (c.energy * cos_f(angleTerm)) / d2;
+}
+#undef RT_CORNER_SKIPPED
+RT_DEV float cluster_importance(f3 spPos, const DevLTNode& c) {
+    // (wave-uniform: one lane whose box is not flat sends the whole wave down the general path; "flat" = the same BITS, so the skipped corners are
+    // exact duplicates down to the sign of a zero)
+    if (__ballot(__float_as_uint(c.lo[1]) != __float_as_uint(c.hi[1])) == 0ull) return cluster_importance_t<1>(spPos, c);
+    if (__ballot(__float_as_uint(c.lo[0]) != __float_as_uint(c.hi[0])) == 0ull) return cluster_importance_t<0>(spPos, c);
+    if (__ballot(__float_as_uint(c.lo[2]) != __float_as_uint(c.hi[2])) == 0ull) return cluster_importance_t<2>(spPos, c);
+    return cluster_importance_t<-1>(spPos, c);
 }
 RT_DEV uint32_t lt_descend(const DevLTNode* nodes, uint32_t idx, f3 spPos, float& r, float& pmf) {
     const uint32_t l = nodes[idx].left, rt_ = nodes[idx].rightOrEmitter;

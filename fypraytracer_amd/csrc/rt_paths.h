@@ -333,7 +333,10 @@ __global__ __launch_bounds__(kBlock) void k_nee_mis(DevScene sc, DevCamera cam, 
 }
 
 // top of the bounce loop (R.cu:1452-1570) for the paths nee_consume listed
-__global__ __launch_bounds__(kBlock) void k_nee_emit(DevScene sc, DevSettings st, const uint32_t* pixelList, const uint32_t* count, float4* state, uint32_t stateStride,
+#ifndef RT_NEE_EMIT_WAVES
+#define RT_NEE_EMIT_WAVES __attribute__((amdgpu_waves_per_eu(5)))      // (the four flat-axis variants of the cluster importance raise the allocator's choice to 100 VGPRs = 4 waves; 96 fit without a spill)
+#endif
+__global__ __launch_bounds__(kBlock) RT_NEE_EMIT_WAVES void k_nee_emit(DevScene sc, DevSettings st, const uint32_t* pixelList, const uint32_t* count, float4* state, uint32_t stateStride,
                                                      float4* raysOut, uint32_t raysPer) {
     const uint32_t n = *count;
     for (uint32_t j = blockIdx.x * (uint32_t)kBlock + threadIdx.x; j < n; j += gridDim.x * (uint32_t)kBlock) {
